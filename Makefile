@@ -1,0 +1,40 @@
+# Top-level build: the HIP library (the product), the C host program, the oracle (test infrastructure)
+# and the microbenchmark.  gfx950 only.  `python -c "import __graft_entry__ as g; g.build()"` runs this.
+HIPCC   ?= hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG     := mini-nbody_amd
+CSRC    := $(PKG)/csrc
+# -ffp-contract=off: products are fused only where the source says fma (rounding points are part of the contract)
+# -fno-slp-vectorize: v_pk_*_f32 costs 4 cycles on gfx950 (profiles/r01_microbench_valu_issue.txt): no gain, more registers
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function
+
+all: lib host oracle microbench
+
+lib: $(PKG)/libnbody_hip.so
+$(PKG)/libnbody_hip.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp include/nbody.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/nbody_hip.hip -ldl
+
+# C host program (north_star: "host code stays in C"): links only the C-ABI
+host: build/nbody
+build/nbody: $(PKG)/host/nbody.c include/nbody.h include/nbody_ic.h $(PKG)/libnbody_hip.so
+	@mkdir -p build
+	$(CC) -std=c11 -O2 -Wall -Iinclude -o $@ $(PKG)/host/nbody.c -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,/opt/rocm/lib -lm
+
+oracle:
+	$(MAKE) -C oracle
+
+microbench: build/microbench
+build/microbench: $(CSRC)/microbench.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
+isa: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp
+	@mkdir -p build/isa
+	cd build/isa && $(HIPCC) $(HIPFLAGS) -c ../../$(CSRC)/nbody_hip.hip -save-temps -Rpass-analysis=kernel-resource-usage -o nbody_hip.o 2> resource_usage.txt
+
+clean:
+	rm -rf build $(PKG)/libnbody_hip.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib host oracle microbench isa clean

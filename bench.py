@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — billion pair-interactions/s of the all-pairs force path (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over all N bodies: force accumulation over all N^2 ordered pairs
+(self included, S/top_level.vhd:237-243), kick, drift — nbody_step() of include/nbody.h, state resident
+in HBM before the timed region starts.  Workload: N = 1,048,576 fp32 (BASELINE configs[2]/[3], the
+configuration the metric is quoted on); with N GPUs the same N is sharded by body (strong scaling) and
+the positions travel by RCCL inside libnbody_hip.so.  torch is used for the rendezvous, the barrier,
+the max-over-ranks and torch.cuda.synchronize() only.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the force kernel at 20 flop per pair
+against the 157.3 TFLOP/s fp32 vector peak, with the kernel's duration measured live by HIP events on
+the library's compute stream; `cpu_baseline` is the oracle (oracle/nbody_ref.c, kind "port": the
+reference is VHDL and has no CPU path) timed on this box's host cores on a bounded row sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 20            # SURVEY.md §8(d) convention (literal count: 18)
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+ISSUE_CYCLES_PER_WAVE_PAIR = 30   # 11 x 2 + 8, measured: profiles/r01_microbench_valu_issue.txt
+
+
+def cpu_baseline(n, seed):
+    """The oracle timed on the host cores: a row sample (first rows x all N sources), sized to take
+    roughly 10-20 s.  Returns the JSON object."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    path = None
+    # same source, tuned for this host if the compiler is here (falls back to the prebuilt x86-64-v3 build)
+    try:
+        tmp = tempfile.mkdtemp(prefix="nbody_ref_native_")
+        path = os.path.join(tmp, "libnbody_ref_native.so")
+        subprocess.run(["gcc", "-std=c11", "-fPIC", "-shared", "-O3", "-march=native", "-fopenmp", "-ffp-contract=off",
+                        "-fno-math-errno", "-fno-trapping-math", "-o", path, os.path.join(ROOT, "oracle", "nbody_ref.c"),
+                        "-lm"], check=True, capture_output=True, timeout=120)
+    except Exception:
+        path = None
+    ora = O.Oracle(fast=True, path=path)
+    cores = ora.num_threads()
+    nb = importlib.import_module("mini-nbody_amd")
+    pos, _ = nb.make_bodies(n, seed=seed)
+    rows = min(n, 4096)
+    ora.forces_f32(pos[:256], pos, rsqrt=O.RSQRT_DIVSQRT)      # warm the thread pool
+    t0 = time.perf_counter()
+    ora.forces_f32(pos[:rows], pos, rsqrt=O.RSQRT_DIVSQRT)
+    t = time.perf_counter() - t0
+    rate = rows * n / t
+    target_s = 12.0
+    rows2 = int(min(n, max(rows, (rate * target_s / n) // 16 * 16)))
+    if rows2 > rows:
+        t0 = time.perf_counter()
+        ora.forces_f32(pos[:rows2], pos, rsqrt=O.RSQRT_DIVSQRT)
+        t = time.perf_counter() - t0
+        rows = rows2
+    return {"value": round(rows * n / t / 1e9, 3), "unit": "billion pair-interactions/s", "cores": cores, "kind": "port",
+            "sample": "oracle/nbody_ref.c (fp32, sequential-j, 1.0f/sqrtf), first %d of %d rows x all %d sources, %.1f s, "
+                      "gcc -O3 %s -fopenmp" % (rows, n, n, t, "-march=native" if path else "-march=x86-64-v3")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 20, help="bodies (default: the metric's N = 1,048,576)")
+    ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--variant", choices=["auto", "smem", "lds", "readlane"], default="auto")
+    ap.add_argument("--iblock", type=int, default=0)
+    ap.add_argument("--jsub", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", choices=["ring", "allgather"], default="ring")
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    nb = importlib.import_module("mini-nbody_amd")
+    from importlib import import_module
+    D = import_module("mini-nbody_amd.distributed")
+
+    rank, world, local = D.env_rank()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    os.environ.setdefault("NBODY_DEVICE", str(local % torch.cuda.device_count()))
+    import torch.distributed as dist
+    if world > 1:
+        D.init_process_group(backend="gloo")   # control plane only; the data path is RCCL inside the library
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    n = args.n
+    eng = D.make_engine(n, fp64=args.fp64, tile=args.tile)
+    eng.set_option(nb.OPT_VARIANT, {"auto": nb.VARIANT_AUTO, "smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS,
+                                    "readlane": nb.VARIANT_READLANE}[args.variant])
+    eng.set_option(nb.OPT_IBLOCK, args.iblock)
+    eng.set_option(nb.OPT_JSUB, args.jsub)
+    eng.set_option(nb.OPT_COMM, nb.COMM_ALLGATHER if args.comm == "allgather" else nb.COMM_RING)
+    eng.set_option(nb.OPT_OVERLAP, 0 if args.no_overlap else 1)
+    import numpy as np
+    pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
+    eng.upload(pos, vel)                      # inputs resident in HBM before the timed region
+    dt = 0.01
+
+    eng.step(dt, args.warmup)
+    eng.sync()
+    eng.set_option(nb.OPT_TIMING, 1)
+    eng.kernel_time(reset=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(dt, args.steps)                  # EXACTLY K steps
+    eng.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.kernel_time(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+    cfg = eng.config
+    p1, _ = eng.download()
+    finite = bool(np.isfinite(p1).all())
+
+    if rank == 0:
+        pairs_per_step = float(n) * float(n)
+        value = pairs_per_step * args.steps / elapsed / 1e9
+        n_local = cfg["n_local"]
+        # force kernel: per launch this rank's share of the pairs; duration from HIP events on the compute stream
+        launches_per_step = max(1, launches // max(1, args.steps))
+        pairs_per_launch = float(n_local) * float(n) / launches_per_step
+        avg_launch_s = kernel_ms * 1e-3 / max(1, launches)
+        kernel_rate = pairs_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0   # pairs/s on one GPU
+        achieved_tflops = kernel_rate * FLOP_PER_PAIR / 1e12
+        cu, clk = eng.info(nb._lib.INFO_CU_COUNT), eng.info(nb._lib.INFO_CLOCK_KHZ) * 1e3
+        issue_bound = cu * 4 * 64.0 / ISSUE_CYCLES_PER_WAVE_PAIR * clk   # pairs/s at the nominal clock
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
+        if os.path.exists(pmc) and not args.fp64 and n == (1 << 20) and world == 1:
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofline",
+            "value": round(value, 2), "unit": "billion pair-interactions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.fp64 else "f32", "data": "synthetic",
+            "config": {"workload": "N=%d %s all-pairs softened gravity, leapfrog kick-drift, dt=0.01, seed %d"
+                                   % (n, "fp64" if args.fp64 else "fp32", args.seed),
+                       "n_bodies": n, "pairs_per_step": pairs_per_step, "parallelism": "bodies sharded over %d GPU(s)" % world,
+                       "kernel": cfg, "comm": args.comm if world > 1 else None, "finite": finite},
+            "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 2), "peak": PEAK_FP32_VECTOR_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
+                         "flop_per_pair": FLOP_PER_PAIR, "kernel_ms_avg": round(avg_launch_s * 1e3, 4),
+                         "kernel_launches": launches, "kernel_gpairs_per_s": round(kernel_rate / 1e9, 1),
+                         "issue_bound_gpairs_per_s": round(issue_bound / 1e9, 1),
+                         "frac_of_issue_bound": round(kernel_rate / issue_bound, 4) if issue_bound else None,
+                         "note": "VALU-issue-bound (11 full-rate + 1 quarter-rate op per pair = 30 cycles per wave64); "
+                                 "the fp32 MFMA peak is the same 157.3 TFLOP/s but the path has no contraction to put on it"},
+        }
+        if args.fp64:
+            out["roofline"]["peak"] = 78.6
+            out["roofline"]["frac"] = round(achieved_tflops / 78.6, 4)
+            out["roofline"]["issue_bound_gpairs_per_s"] = None
+            out["roofline"]["frac_of_issue_bound"] = None
+        if world == 1 and not args.no_cpu_baseline and not args.fp64:
+            out["cpu_baseline"] = cpu_baseline(n, args.seed)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

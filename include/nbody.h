@@ -1,0 +1,145 @@
+/* nbody.h — C-ABI of the MI355X all-pairs N-body engine (libnbody_hip.so).
+ *
+ * Plain C99: pointers, ints, floats.  No HIP, torch or C++ types cross this
+ * boundary.  The library behind it is hand-written HIP for gfx950
+ * (mini-nbody_amd/csrc/nbody_hip.hip); there is no CPU fallback: every entry
+ * point fails with NBODY_ERR_NO_DEVICE when no GPU is usable.
+ *
+ * WHAT EACH ENTRY POINT REPLACES.  The reference (/root/reference, a VHDL FPGA
+ * design; "S/" = vec_add.srcs/sources_1/new/) has no function ABI: its only
+ * boundary is a memory-mapped mailbox:
+ *   - bodies in:  128-bit words {x, y, z, ignored} at word k = 1..N of RAM A    S/top_level.vhd:206-208, 238-240, 280
+ *   - start:      word 0 = {bit 0 BEGIN, bits 46:32 NUM_PTS}                   S/top_level.vhd:184-185
+ *   - forces out: 128-bit words {Fx, Fy, Fz, 0} at word k-1 of RAM B           S/compute_store.vhd:213, 227-242
+ *   - done:       word 0 rewritten with {ticks in bits 63:32}, BEGIN reads 0   S/top_level.vhd:146, 255-263
+ *   - one request in flight; BEGIN ignored while busy                          S/top_level.vhd:180-186
+ * The names bodyForce()/integrate() and the {pos, vel} layout come from
+ * BASELINE.json's north_star (the host program they would belong to is not in
+ * the reference tree); the 16-byte body word is the reference's.
+ *
+ * Conventions: every function returns 0 (NBODY_OK) on success; a positive value
+ * < 1000 is a hipError_t, 1000..1999 an NBODY_ERR_*, 2000 + r an ncclResult_t r.
+ * The caller owns host buffers, the library owns device buffers.  One context
+ * per process, not thread-safe (the reference's single in-flight request).
+ */
+#ifndef NBODY_H
+#define NBODY_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_OK 0
+#define NBODY_ERR_NOT_INIT 1001
+#define NBODY_ERR_ARG 1002
+#define NBODY_ERR_NO_DEVICE 1003
+#define NBODY_ERR_RCCL_LOAD 1004
+#define NBODY_ERR_STATE 1005
+#define NBODY_ERR_UNSUPPORTED 1006
+
+/* Structure of arrays: two arrays of N 16-byte words.
+ * pos[4i..4i+3] = {x, y, z, w}   (w is carried, never read by the force: S/top_level.vhd:206-208 ignores bits 127:96)
+ * vel[4i..4i+3] = {vx, vy, vz, 0} */
+typedef struct { float *pos, *vel; } BodySystem;
+typedef struct { double *pos, *vel; } BodySystemD; /* fp64 configuration: N x 4 doubles (32-byte words) */
+
+/* ---- options (nbody_set_option; all have working defaults) ---- */
+enum {
+  NBODY_OPT_VARIANT = 1,   /* how source bodies reach the lanes: NBODY_VARIANT_* */
+  NBODY_OPT_IBLOCK = 2,    /* bodies per lane (register blocking) 1, 2, 4 or 8; 0 = auto */
+  NBODY_OPT_JSUB = 3,      /* sub-segments per source slice; 0 = auto */
+  NBODY_OPT_JSLICES = 4,   /* single-GPU only: number of source slices (to reproduce a P-GPU summation order bit for bit) */
+  NBODY_OPT_ARITH = 5,     /* NBODY_ARITH_* */
+  NBODY_OPT_SUM_ORDER = 6, /* NBODY_SUM_* */
+  NBODY_OPT_TIMING = 7,    /* 1: HIP events around every force kernel (nbody_kernel_time) */
+  NBODY_OPT_COMM = 8,      /* NBODY_COMM_* (multi-GPU) */
+  NBODY_OPT_OVERLAP = 9    /* multi-GPU: 1 = start on the rank's own slice while the others travel (default), 0 = gather first */
+};
+enum { NBODY_VARIANT_AUTO = 0,
+       NBODY_VARIANT_SMEM = 1,     /* wave-uniform scalar loads (s_load_dwordx16) into SGPRs: no LDS, no VALU cost */
+       NBODY_VARIANT_LDS = 2,      /* `tile` bodies staged in LDS per workgroup, broadcast ds_read_b128 */
+       NBODY_VARIANT_READLANE = 3  /* 64-body wave tile in VGPRs, v_readlane broadcast ("__shfl") */ };
+enum { NBODY_ARITH_FMA3 = 0,       /* d2 = fma(dx,dx,fma(dy,dy,fma(dz,dz,eps))): 11 VALU + v_rsq_f32 per pair.  THE TIMED MODE */
+       NBODY_ARITH_REFERENCE = 1,  /* d2 = (dx*dx+dy*dy)+fma(dz,dz,eps): the RTL's rounding points, S/dxy.vhd:113-122, S/dzsoft.vhd:201-202, S/dxyz_soft.vhd:149-150 */
+       NBODY_ARITH_STRICT = 2,     /* FMA3 with 1/sqrt rounded once from an fp64 evaluation instead of v_rsq_f32 (1 ulp):
+                                      every operation is then IEEE-exact and the result is bit-identical to the CPU oracle */
+       NBODY_ARITH_REFERENCE_STRICT = 3 /* REFERENCE roundings + strict 1/sqrt */ };
+enum { NBODY_SUM_SEQ = 0,          /* one accumulator per segment, sources ascending (S/top_level.vhd:233-254) */
+       NBODY_SUM_FPGA16 = 1        /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */ };
+enum { NBODY_COMM_RING = 0,        /* P-1 ncclSend/ncclRecv ring steps, one event per arriving slice */
+       NBODY_COMM_ALLGATHER = 1    /* one in-place ncclAllGather */ };
+
+/* ---- info keys (nbody_get_info) ---- */
+enum { NBODY_INFO_N = 1, NBODY_INFO_N_LOCAL, NBODY_INFO_FIRST_BODY, NBODY_INFO_RANK, NBODY_INFO_NRANKS,
+       NBODY_INFO_VARIANT, NBODY_INFO_IBLOCK, NBODY_INFO_JSUB, NBODY_INFO_NSEG, NBODY_INFO_DEVICE,
+       NBODY_INFO_CU_COUNT, NBODY_INFO_CLOCK_KHZ, NBODY_INFO_FP64, NBODY_INFO_TILE, NBODY_INFO_STEPS_DONE };
+
+/* ---- lifetime ----
+ * Replaces: power-up of the PL design + the ps_pl RAM allocation (S/top_level.vhd:100-117, 148-163). */
+
+/* One process driving `ngpus` devices (ngpus = 1: device NBODY_DEVICE or 0).  tile: LDS tile in
+ * bodies for NBODY_VARIANT_LDS (64..1024, multiple of 64; 0 = 256). */
+int nbody_init(int n, int ngpus, int fp64, int tile);
+/* One process per GPU (the torch.distributed / MPI launch): rank 0 calls nbody_unique_id() and
+ * broadcasts the 128 bytes by its own means; every rank then calls nbody_init_rank().  Device =
+ * NBODY_DEVICE, else LOCAL_RANK, else rank modulo the visible device count. */
+int nbody_unique_id(void *uid128);
+int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void *uid128);
+void nbody_shutdown(void);
+
+int nbody_set_option(int key, int value);
+int nbody_get_info(int key, long long *value);
+const char *nbody_error_string(int code);
+
+/* ---- state transfer (host <-> device mirrors) ----
+ * Replaces: the PS writing bodies to RAM A words 1..N and reading RAM B (S/top_level.vhd:206-208; S/compute_store.vhd:242).
+ * Arrays are always the FULL N bodies, on every rank; a rank keeps its own slice of vel. */
+int nbody_upload(const BodySystem *host);
+int nbody_download(BodySystem *host);
+int nbody_upload_d(const BodySystemD *host);
+int nbody_download_d(BodySystemD *host);
+
+/* ---- the path ---- */
+
+/* v_i += dt * sum_j (r_j - r_i) * (|r_j - r_i|^2 + 1e-9f)^(-3/2), all j including i; pos is read-only.
+ * Host pointers, n must equal the n of nbody_init.  (upload, force kernel + kick, download of vel.)
+ * Replaces one full pass of the FSM, S/top_level.vhd:176-272, followed by the host's kick. */
+int bodyForce(float *pos, float *vel, float dt, int n);
+/* r_i += v_i * dt.  Host pointers. */
+int integrate(float *pos, const float *vel, float dt, int n);
+int bodyForce_d(double *pos, double *vel, double dt, int n);
+int integrate_d(double *pos, const double *vel, double dt, int n);
+
+/* Device-resident loop: nsteps x { bodyForce; integrate } on the uploaded state, no host round trip
+ * per step; asynchronous (nbody_sync or nbody_download waits).  THE TIMED PATH. */
+int nbody_step(float dt, int nsteps);
+int nbody_step_d(double dt, int nsteps);
+int nbody_sync(void);
+
+/* Force-only entry point with the reference's word layouts: pos_words = N x {x, y, z, ignored}
+ * (S/top_level.vhd:206-208), force_words = N x {Fx, Fy, Fz, 0} (S/compute_store.vhd:213, 242). */
+int nbody_forces(const float *pos_words, float *force_words, int n);
+int nbody_forces_d(const double *pos_words, double *force_words, int n);
+/* Forces on `n_rows` bodies starting at `first_row`, from the state already on the device
+ * (row-sampled parity checks at N = 1M). */
+int nbody_forces_rows(int first_row, int n_rows, float *force_words);
+
+/* The reference's mailbox, verbatim: ram_a = (N+1) 16-byte words, word 0 = control
+ * {bit 0 BEGIN, bits 46:32 NUM_PTS}; ram_b = N words of forces.  On return word 0 of ram_a has
+ * BEGIN = 0 and bits 63:32 = elapsed time in units of 1000 clocks of `clock_khz` (0: 300 MHz),
+ * as S/top_level.vhd:121-146 counts them.  Returns NBODY_ERR_STATE if BEGIN is not set. */
+int nbody_mailbox_run(void *ram_a, void *ram_b, int clock_khz);
+
+/* Sum of HIP-event durations of the force kernels since the last reset (NBODY_OPT_TIMING = 1). */
+int nbody_kernel_time(double *ms_total, long long *launches, int reset);
+
+/* Device pointers of the resident state (for zero-copy interop with a framework that owns a view):
+ * which = 0 current positions (full N), 1 velocities (own slice), 2 last forces (own slice). */
+int nbody_device_ptr(int which, void **ptr, size_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_H */

@@ -1,0 +1,16 @@
+"""mini-nbody_amd — MI355X-native all-pairs N-body force path.
+
+The package holds only what the path needs: csrc/ (HIP kernels + the C-ABI of
+include/nbody.h), host/ (the C host program) and this thin Python mirror of the
+interface.  The directory name has a hyphen; import it with
+importlib.import_module("mini-nbody_amd") or through the `mini_nbody_amd` alias
+module at the repository root.
+"""
+from . import _lib, bodies, mailbox, sharding  # noqa: F401
+from ._lib import (ARITH_FMA3, ARITH_REFERENCE, ARITH_REFERENCE_STRICT, ARITH_STRICT, COMM_ALLGATHER, COMM_RING, OPT_ARITH, OPT_COMM, OPT_IBLOCK,  # noqa: F401
+                   OPT_JSLICES, OPT_JSUB, OPT_OVERLAP, OPT_SUM_ORDER, OPT_TIMING, OPT_VARIANT, SUM_FPGA16, SUM_SEQ,
+                   VARIANT_AUTO, VARIANT_LDS, VARIANT_READLANE, VARIANT_SMEM, NBodyError)
+from .bodies import make_bodies  # noqa: F401
+from .engine import NBody, unique_id  # noqa: F401
+
+__all__ = ["NBody", "NBodyError", "make_bodies", "unique_id", "bodies", "mailbox", "sharding"]

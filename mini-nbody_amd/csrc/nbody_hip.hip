@@ -1,0 +1,875 @@
+// nbody_hip.hip — the C-ABI of include/nbody.h on top of the kernels in
+// nbody_kernels.hpp.  gfx950 only; no CPU fallback anywhere in this file.
+//
+// Data layout in HBM (per rank; N bodies in total, the rank owns n_local of
+// them starting at first_body):
+//   pos[2]   2 x N words      full position set, double-buffered: a step reads pos[cur] and writes the
+//                             rank's slice of pos[cur^1]; the other slices of pos[cur^1] arrive over xGMI
+//   vel      n_local words    never leaves the rank
+//   partial  nseg x n_local   per-source-segment partial forces (unused when nseg == 1: fused epilogue)
+//   force    n_local words    last combined forces (mailbox / parity entry points)
+// word = {x,y,z,w}: 16 B (fp32) or 32 B (fp64) — the reference's RAM word, S/top_level.vhd:206-208.
+//
+// Multi-GPU: bodies are sharded by i; every step each rank
+// needs all N positions.  Sources are cut into one slice per rank (x `sub`
+// pieces); a step first runs on the rank's own slice while the other slices
+// travel (ring of ncclSend/ncclRecv on a second stream, or peer copies when one
+// process drives all GPUs), then on the arrived slices.  Partial sums are kept
+// per segment and combined in ascending source order, so the result is
+// bit-identical for every arrival order and for a single GPU configured with
+// the same segmentation.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only; the library is resolved with dlopen when nranks > 1
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/nbody.h"
+#include "nbody_kernels.hpp"
+
+using namespace nbk;
+
+namespace {
+
+#define HIPC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_line = __LINE__; return (int)e_; } } while (0)
+#define NBC(expr) do { int e_ = (expr); if (e_ != NBODY_OK) return e_; } while (0)
+#define NCCLC(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { g_last_line = __LINE__; return 2000 + (int)r_; } } while (0)
+
+int g_last_line = 0;
+
+constexpr int kMaxLocal = 16;
+constexpr int kMaxRanks = 64;
+constexpr int kTimerRing = 256;
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+  if (g_rccl.handle) return NBODY_OK;
+  // librccl.so.1 already mapped by the host framework (e.g. torch) is reused: same SONAME.
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  if (!h) return NBODY_ERR_RCCL_LOAD;
+#define SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return NBODY_ERR_RCCL_LOAD; } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+  SYM(AllGather, "ncclAllGather");
+#undef SYM
+  g_rccl.handle = h;
+  return NBODY_OK;
+}
+
+struct Local {
+  int device = 0, rank = 0;
+  int first = 0, n_local = 0;          // owned bodies
+  hipStream_t compute = nullptr, comm = nullptr;
+  void* pos[2] = {nullptr, nullptr};
+  void* vel = nullptr;
+  void* partial = nullptr;
+  void* force = nullptr;
+  void* vel_full = nullptr;            // download scratch (multi-process)
+  int cur = 0;
+  bool all_present = true;             // pos[cur] holds every slice
+  hipEvent_t ev_own_ready = nullptr;   // the rank's slice of pos[cur] is written
+  hipEvent_t ev_gather[kMaxRanks] = {};
+  hipEvent_t ev_compute_done = nullptr;
+  ncclComm_t comm_h = nullptr;
+  // force-kernel timing
+  hipEvent_t t0[kTimerRing] = {}, t1[kTimerRing] = {};
+  int t_head = 0, t_count = 0;
+  double t_ms = 0.0;
+  long long t_launches = 0;
+};
+
+struct Options {
+  int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
+  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_RING, overlap = 1;
+};
+
+struct Global {
+  bool init = false;
+  int n = 0, fp64 = 0, tile = 256;
+  int nranks = 1, nlocal = 0;
+  bool multiprocess = false;
+  Local loc[kMaxLocal];
+  Options opt;
+  // resolved launch configuration
+  int variant = NBODY_VARIANT_SMEM, R = 4, sub = 1, nslices = 1, nseg = 1;
+  size_t partial_words = 0;
+  int cu_count = 0, clock_khz = 0;
+  long long steps_done = 0;
+};
+Global g;
+
+inline size_t word_bytes() { return g.fp64 ? 32 : 16; }
+inline char* word_ptr(void* base, size_t word) { return (char*)base + word * word_bytes(); }
+
+int blocks_for(int rows, int R) { return (rows + kBlock * R - 1) / (kBlock * R); }
+
+// Choose R (bodies per lane) and sub (pieces per source slice) so that one launch over ONE slice
+// already puts >= 4 waves on every SIMD (1024 workgroups of 4 waves on 256 CUs): the 11+1 issue
+// mix needs 3-4 waves per SIMD to reach 30 cycles per pair-wave (profiles/r01_microbench_valu_issue.txt).
+void resolve_config() {
+  const int n_local = g.loc[0].n_local > 0 ? g.loc[0].n_local : 1;
+  g.nslices = g.nranks > 1 ? g.nranks : (g.opt.jslices > 0 ? g.opt.jslices : 1);
+  g.variant = g.opt.variant == NBODY_VARIANT_AUTO ? NBODY_VARIANT_SMEM : g.opt.variant;
+  if (g.fp64) g.variant = NBODY_VARIANT_SMEM;
+  int R = g.opt.iblock;
+  const int target_blocks = 4 * (g.cu_count > 0 ? g.cu_count : 256);
+  if (R == 0) {
+    R = g.fp64 ? 2 : 4;
+    while (R > 1 && blocks_for(n_local, R) < target_blocks / 4) R >>= 1;
+  }
+  if (g.fp64 && R > 4) R = 4;
+  if (g.opt.sum_order == NBODY_SUM_FPGA16 && !g.fp64) R = 1;
+  g.R = R;
+  int sub = g.opt.jsub;
+  if (sub == 0) {
+    int b = blocks_for(n_local, R);
+    sub = (target_blocks + b - 1) / b;
+    int slice_len = g.n / g.nslices;
+    int max_sub = std::max(1, slice_len / 256);   // keep >= 256 sources per segment
+    sub = std::max(1, std::min(std::min(sub, 32), max_sub));
+  }
+  g.sub = sub;
+  g.nseg = g.nslices * g.sub;
+}
+
+int alloc_local(Local& L) {
+  HIPC(hipSetDevice(L.device));
+  HIPC(hipStreamCreateWithFlags(&L.compute, hipStreamNonBlocking));
+  HIPC(hipStreamCreateWithFlags(&L.comm, hipStreamNonBlocking));
+  const size_t wb = word_bytes();
+  const size_t pad = 64;   // words of slack after the arrays (never read by the kernels; keeps SMEM groups in-bounds by construction anyway)
+  for (int b = 0; b < 2; ++b) { HIPC(hipMalloc(&L.pos[b], (g.n + pad) * wb)); HIPC(hipMemset(L.pos[b], 0, (g.n + pad) * wb)); }
+  HIPC(hipMalloc(&L.vel, (L.n_local + pad) * wb));
+  HIPC(hipMalloc(&L.force, (L.n_local + pad) * wb));
+  HIPC(hipMemset(L.vel, 0, (L.n_local + pad) * wb));
+  HIPC(hipMemset(L.force, 0, (L.n_local + pad) * wb));
+  HIPC(hipEventCreateWithFlags(&L.ev_own_ready, hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&L.ev_compute_done, hipEventDisableTiming));
+  for (int s = 0; s < g.nranks && s < kMaxRanks; ++s) HIPC(hipEventCreateWithFlags(&L.ev_gather[s], hipEventDisableTiming));
+  for (int k = 0; k < kTimerRing; ++k) { HIPC(hipEventCreate(&L.t0[k])); HIPC(hipEventCreate(&L.t1[k])); }
+  return NBODY_OK;
+}
+
+int ensure_partial(Local& L) {
+  size_t need = (size_t)g.nseg * (size_t)L.n_local;
+  if (L.partial && need <= g.partial_words) return NBODY_OK;
+  HIPC(hipSetDevice(L.device));
+  if (L.partial) { HIPC(hipFree(L.partial)); L.partial = nullptr; }
+  HIPC(hipMalloc(&L.partial, (need + 64) * word_bytes()));
+  return NBODY_OK;
+}
+
+int reconfigure() {
+  resolve_config();
+  size_t maxneed = 0;
+  for (int l = 0; l < g.nlocal; ++l) {
+    NBC(ensure_partial(g.loc[l]));
+    maxneed = std::max(maxneed, (size_t)g.nseg * (size_t)g.loc[l].n_local);
+  }
+  g.partial_words = std::max(g.partial_words, maxneed);
+  return NBODY_OK;
+}
+
+// ---- force-kernel timing ring ----
+int timer_drain(Local& L, int keep) {
+  while (L.t_count > keep) {
+    int idx = (L.t_head - L.t_count + 2 * kTimerRing) % kTimerRing;
+    HIPC(hipEventSynchronize(L.t1[idx]));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, L.t0[idx], L.t1[idx]));
+    L.t_ms += ms;
+    L.t_launches += 1;
+    L.t_count--;
+  }
+  return NBODY_OK;
+}
+
+template <typename K>
+int launch_timed(Local& L, K kernel, dim3 grid, const ForceArgs& a) {
+  int idx = -1;
+  if (g.opt.timing) {
+    if (L.t_count == kTimerRing) NBC(timer_drain(L, kTimerRing / 2));
+    idx = L.t_head;
+    HIPC(hipEventRecord(L.t0[idx], L.compute));
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, L.compute, a);
+  HIPC(hipGetLastError());
+  if (idx >= 0) {
+    HIPC(hipEventRecord(L.t1[idx], L.compute));
+    L.t_head = (L.t_head + 1) % kTimerRing;
+    L.t_count++;
+  }
+  return NBODY_OK;
+}
+
+template <int R, int ARITH>
+int launch_f32_RA(Local& L, dim3 grid, const ForceArgs& a) {
+  if constexpr (R == 8) {   // 8 bodies per lane only exists for the SMEM variant
+    return launch_timed(L, force_smem_f32<R, ARITH>, grid, a);
+  } else {
+    switch (g.variant) {
+      case NBODY_VARIANT_LDS:
+        if (g.tile >= 1024) return launch_timed(L, force_lds_f32<R, ARITH, 1024>, grid, a);
+        if (g.tile >= 512) return launch_timed(L, force_lds_f32<R, ARITH, 512>, grid, a);
+        return launch_timed(L, force_lds_f32<R, ARITH, 256>, grid, a);
+      case NBODY_VARIANT_READLANE:
+        return launch_timed(L, force_readlane_f32<R, ARITH>, grid, a);
+      default:
+        return launch_timed(L, force_smem_f32<R, ARITH>, grid, a);
+    }
+  }
+}
+
+template <int R>
+int launch_f32_R(Local& L, dim3 grid, const ForceArgs& a) {
+  switch (g.opt.arith) {
+    case NBODY_ARITH_REFERENCE: return launch_f32_RA<R, 1>(L, grid, a);
+    case NBODY_ARITH_STRICT: return launch_f32_RA<R, 2>(L, grid, a);
+    case NBODY_ARITH_REFERENCE_STRICT: return launch_f32_RA<R, 3>(L, grid, a);
+    default: return launch_f32_RA<R, 0>(L, grid, a);
+  }
+}
+
+// Launch the force kernel of local L for rows [row0, row0+row_count) against `nsl` source slices
+// starting at slice_start and descending (ring arrival order).  fused only when nseg == 1.
+int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, bool fused, float dt, double dt64) {
+  if (row_count <= 0 || nsl <= 0) return NBODY_OK;
+  HIPC(hipSetDevice(L.device));
+  ForceArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = L.pos[L.cur];
+  a.rows = word_ptr(L.pos[L.cur], (size_t)L.first);
+  a.partial = L.partial;
+  a.vel = L.vel;
+  a.pos_next_rows = word_ptr(L.pos[L.cur ^ 1], (size_t)L.first);
+  a.n_src = g.n; a.n_rows = L.n_local; a.row0 = row0; a.row_count = row_count;
+  a.nslices = g.nslices; a.sub = g.sub; a.slice_start = slice_start;
+  a.fused = fused ? 1 : 0;
+  a.fpga16 = g.opt.sum_order == NBODY_SUM_FPGA16;
+  a.dt = dt; a.dt64 = dt64;
+  const int R = g.R;
+  dim3 grid(blocks_for(row_count, R), nsl * g.sub, 1);
+  if (g.fp64) {
+    switch (R) {
+      case 1: return launch_timed(L, force_smem_f64<1>, grid, a);
+      case 2: return launch_timed(L, force_smem_f64<2>, grid, a);
+      default: return launch_timed(L, force_smem_f64<4>, grid, a);
+    }
+  }
+  if (a.fpga16) {
+    grid.x = blocks_for(row_count, 1);
+    switch (g.opt.arith) {
+      case NBODY_ARITH_REFERENCE: return launch_timed(L, force_fpga16_f32<1>, grid, a);
+      case NBODY_ARITH_STRICT: return launch_timed(L, force_fpga16_f32<2>, grid, a);
+      case NBODY_ARITH_REFERENCE_STRICT: return launch_timed(L, force_fpga16_f32<3>, grid, a);
+      default: return launch_timed(L, force_fpga16_f32<0>, grid, a);
+    }
+  }
+  switch (R) {
+    case 1: return launch_f32_R<1>(L, grid, a);
+    case 2: return launch_f32_R<2>(L, grid, a);
+    case 8: return launch_f32_R<8>(L, grid, a);
+    default: return launch_f32_R<4>(L, grid, a);
+  }
+}
+
+int launch_combine(Local& L, int row0, int row_count, bool kick, bool drift, bool store_force, float dt, double dt64) {
+  if (row_count <= 0) return NBODY_OK;
+  HIPC(hipSetDevice(L.device));
+  CombineArgs c;
+  memset(&c, 0, sizeof(c));
+  c.partial = L.partial;
+  c.pos_rows = word_ptr(L.pos[L.cur], (size_t)L.first);
+  c.pos_next_rows = word_ptr(L.pos[L.cur ^ 1], (size_t)L.first);
+  c.vel = L.vel;
+  c.force_out = store_force ? L.force : nullptr;
+  c.nseg = g.nseg; c.n_rows = L.n_local; c.row0 = row0; c.row_count = row_count;
+  c.do_kick = kick; c.do_drift = drift; c.dt = dt; c.dt64 = dt64;
+  dim3 grid((row_count + kBlock - 1) / kBlock);
+  if (g.fp64) hipLaunchKernelGGL((combine_kernel<double, d4>), grid, dim3(kBlock), 0, L.compute, c);
+  else hipLaunchKernelGGL((combine_kernel<float, f4>), grid, dim3(kBlock), 0, L.compute, c);
+  HIPC(hipGetLastError());
+  return NBODY_OK;
+}
+
+inline int ring_slice(int rank, int s) { int q = (rank - s) % g.nranks; return q < 0 ? q + g.nranks : q; }
+
+// Bring the other ranks' slices of pos[buf] to every local.  Enqueued on the comm streams; records
+// ev_gather[s] (s = 1..P-1) as slices arrive.  Sources are valid after their owner's ev_own_ready.
+int enqueue_gather(int buf) {
+  const int P = g.nranks;
+  if (P == 1) return NBODY_OK;
+  const size_t wb = word_bytes();
+  if (!g.multiprocess) {
+    // one process, P devices: every local pulls each remote slice straight from its owner (xGMI is
+    // fully connected: one hop, all links busy), in ring order so arrival order matches the RCCL path.
+    for (int l = 0; l < g.nlocal; ++l) {
+      Local& L = g.loc[l];
+      HIPC(hipSetDevice(L.device));
+      for (int s = 1; s < P; ++s) {
+        Local& O = g.loc[ring_slice(L.rank, s)];
+        HIPC(hipStreamWaitEvent(L.comm, O.ev_own_ready, 0));
+        HIPC(hipMemcpyPeerAsync(word_ptr(L.pos[buf], O.first), L.device, word_ptr(O.pos[buf], O.first), O.device,
+                                (size_t)O.n_local * wb, L.comm));
+        HIPC(hipEventRecord(L.ev_gather[s], L.comm));
+      }
+    }
+    return NBODY_OK;
+  }
+  Local& L = g.loc[0];
+  HIPC(hipSetDevice(L.device));
+  HIPC(hipStreamWaitEvent(L.comm, L.ev_own_ready, 0));
+  const bool even = (g.n % P) == 0;
+  if (g.opt.comm == NBODY_COMM_ALLGATHER && even) {
+    NCCLC(g_rccl.AllGather(word_ptr(L.pos[buf], L.first), L.pos[buf], (size_t)L.n_local * wb, ncclChar, L.comm_h, L.comm));
+    for (int s = 1; s < P; ++s) HIPC(hipEventRecord(L.ev_gather[s], L.comm));
+    return NBODY_OK;
+  }
+  const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
+  for (int s = 1; s < P; ++s) {
+    const int qs = ring_slice(L.rank, s - 1);   // forward what arrived last (own slice at s = 1)
+    const int qr = ring_slice(L.rank, s);
+    const int fs = slice_first(qs, g.n, P), ls = slice_first(qs + 1, g.n, P) - fs;
+    const int fr = slice_first(qr, g.n, P), lr = slice_first(qr + 1, g.n, P) - fr;
+    NCCLC(g_rccl.GroupStart());
+    NCCLC(g_rccl.Send(word_ptr(L.pos[buf], fs), (size_t)ls * wb, ncclChar, next, L.comm_h, L.comm));
+    NCCLC(g_rccl.Recv(word_ptr(L.pos[buf], fr), (size_t)lr * wb, ncclChar, prev, L.comm_h, L.comm));
+    NCCLC(g_rccl.GroupEnd());
+    HIPC(hipEventRecord(L.ev_gather[s], L.comm));
+  }
+  return NBODY_OK;
+}
+
+// One step on every local: forces on pos[cur], kick, drift into pos[cur^1], swap.
+int enqueue_step(float dt, double dt64) {
+  const int P = g.nranks;
+  const bool fused = (g.nseg == 1);
+  const bool need_gather = !g.loc[0].all_present;
+  if (need_gather && g.opt.overlap) NBC(enqueue_gather(g.loc[0].cur));
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    if (need_gather && !g.opt.overlap) {
+      // gather first, then one launch over everything
+      if (l == 0) NBC(enqueue_gather(L.cur));
+    }
+    if (P == 1) {
+      NBC(launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fused, dt, dt64));
+    } else if (!need_gather) {
+      NBC(launch_force(L, 0, L.n_local, L.rank, P, false, dt, dt64));
+    } else if (g.opt.overlap) {
+      // own slice now; the others as they arrive (one launch for all of them after the last event:
+      // the transfer is ~100 us against milliseconds of own-slice work)
+      NBC(launch_force(L, 0, L.n_local, L.rank, 1, false, dt, dt64));
+      HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[P - 1], 0));
+      NBC(launch_force(L, 0, L.n_local, ring_slice(L.rank, 1), P - 1, false, dt, dt64));
+    } else {
+      HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[P - 1], 0));
+      NBC(launch_force(L, 0, L.n_local, L.rank, P, false, dt, dt64));
+    }
+    if (!fused) NBC(launch_combine(L, 0, L.n_local, true, true, false, dt, dt64));
+    HIPC(hipEventRecord(L.ev_own_ready, L.compute));
+  }
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    if (P > 1) {
+      // the comm stream must not start the NEXT gather into a buffer this step still reads: it waits
+      // on ev_own_ready (recorded after this step's last kernel) inside enqueue_gather.
+    }
+    L.cur ^= 1;
+    L.all_present = (P == 1);
+  }
+  g.steps_done++;
+  return NBODY_OK;
+}
+
+int sync_all() {
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipStreamSynchronize(L.comm));
+    HIPC(hipStreamSynchronize(L.compute));
+  }
+  return NBODY_OK;
+}
+
+// make pos[cur] complete on every local (after a step only the own slice is there)
+int complete_positions() {
+  if (g.nranks == 1 || g.loc[0].all_present) return NBODY_OK;
+  NBC(enqueue_gather(g.loc[0].cur));
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[g.nranks - 1], 0));
+    L.all_present = true;
+  }
+  return sync_all();
+}
+
+int pick_device(int rank, int ndev) {
+  const char* e = getenv("NBODY_DEVICE");
+  if (e && *e) return atoi(e) % ndev;
+  e = getenv("LOCAL_RANK");
+  if (e && *e) return atoi(e) % ndev;
+  return rank % ndev;
+}
+
+int init_common(int n, int fp64, int tile) {
+  if (n <= 0 || n > (1 << 30)) return NBODY_ERR_ARG;
+  if (tile == 0) tile = 256;
+  if (tile < 64 || tile > 1024 || tile % 64) return NBODY_ERR_ARG;
+  g.n = n; g.fp64 = fp64 ? 1 : 0; g.tile = tile;
+  g.steps_done = 0; g.partial_words = 0;
+  return NBODY_OK;
+}
+
+int device_count(int* ndev) {
+  hipError_t e = hipGetDeviceCount(ndev);
+  if (e != hipSuccess || *ndev <= 0) return NBODY_ERR_NO_DEVICE;
+  return NBODY_OK;
+}
+
+void free_local(Local& L) {
+  if (L.compute == nullptr && L.pos[0] == nullptr) return;
+  (void)hipSetDevice(L.device);
+  if (L.compute) (void)hipStreamSynchronize(L.compute);
+  if (L.comm) (void)hipStreamSynchronize(L.comm);
+  if (L.comm_h && g_rccl.CommDestroy) g_rccl.CommDestroy(L.comm_h);
+  for (int b = 0; b < 2; ++b) if (L.pos[b]) (void)hipFree(L.pos[b]);
+  if (L.vel) (void)hipFree(L.vel);
+  if (L.partial) (void)hipFree(L.partial);
+  if (L.force) (void)hipFree(L.force);
+  if (L.vel_full) (void)hipFree(L.vel_full);
+  if (L.ev_own_ready) (void)hipEventDestroy(L.ev_own_ready);
+  if (L.ev_compute_done) (void)hipEventDestroy(L.ev_compute_done);
+  for (int s = 0; s < kMaxRanks; ++s) if (L.ev_gather[s]) (void)hipEventDestroy(L.ev_gather[s]);
+  for (int k = 0; k < kTimerRing; ++k) { if (L.t0[k]) (void)hipEventDestroy(L.t0[k]); if (L.t1[k]) (void)hipEventDestroy(L.t1[k]); }
+  if (L.compute) (void)hipStreamDestroy(L.compute);
+  if (L.comm) (void)hipStreamDestroy(L.comm);
+  L = Local();
+}
+
+int upload_impl(const void* pos, const void* vel) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!pos || !vel) return NBODY_ERR_ARG;
+  const size_t wb = word_bytes();
+  NBC(sync_all());
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipMemcpyAsync(L.pos[L.cur], pos, (size_t)g.n * wb, hipMemcpyHostToDevice, L.compute));
+    HIPC(hipMemcpyAsync(L.vel, (const char*)vel + (size_t)L.first * wb, (size_t)L.n_local * wb, hipMemcpyHostToDevice, L.compute));
+    HIPC(hipEventRecord(L.ev_own_ready, L.compute));
+    L.all_present = true;
+  }
+  return sync_all();
+}
+
+int gather_vel_multiprocess(Local& L) {
+  const int P = g.nranks;
+  const size_t wb = word_bytes();
+  HIPC(hipSetDevice(L.device));
+  if (!L.vel_full) HIPC(hipMalloc(&L.vel_full, (size_t)(g.n + 64) * wb));
+  HIPC(hipMemcpyAsync(word_ptr(L.vel_full, L.first), L.vel, (size_t)L.n_local * wb, hipMemcpyDeviceToDevice, L.comm));
+  const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
+  for (int s = 1; s < P; ++s) {
+    const int qs = ring_slice(L.rank, s - 1), qr = ring_slice(L.rank, s);
+    const int fs = slice_first(qs, g.n, P), ls = slice_first(qs + 1, g.n, P) - fs;
+    const int fr = slice_first(qr, g.n, P), lr = slice_first(qr + 1, g.n, P) - fr;
+    NCCLC(g_rccl.GroupStart());
+    NCCLC(g_rccl.Send(word_ptr(L.vel_full, fs), (size_t)ls * wb, ncclChar, next, L.comm_h, L.comm));
+    NCCLC(g_rccl.Recv(word_ptr(L.vel_full, fr), (size_t)lr * wb, ncclChar, prev, L.comm_h, L.comm));
+    NCCLC(g_rccl.GroupEnd());
+  }
+  HIPC(hipStreamSynchronize(L.comm));
+  return NBODY_OK;
+}
+
+int download_impl(void* pos, void* vel) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!pos || !vel) return NBODY_ERR_ARG;
+  const size_t wb = word_bytes();
+  NBC(sync_all());
+  if (g.multiprocess && g.nranks > 1) {
+    Local& L = g.loc[0];
+    NBC(complete_positions());
+    NBC(gather_vel_multiprocess(L));
+    HIPC(hipMemcpy(pos, L.pos[L.cur], (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(vel, L.vel_full, (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+  }
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipMemcpy((char*)pos + (size_t)L.first * wb, word_ptr(L.pos[L.cur], L.first), (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy((char*)vel + (size_t)L.first * wb, L.vel, (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
+  }
+  return NBODY_OK;
+}
+
+// forces of rows [row0, row0+count) of every local's slice, from pos[cur] (must be complete)
+int forces_on_device(int row0, int count_or_all) {
+  NBC(reconfigure());
+  NBC(complete_positions());
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    int cnt = count_or_all < 0 ? L.n_local : count_or_all;
+    int r0 = count_or_all < 0 ? 0 : row0;
+    NBC(launch_force(L, r0, cnt, g.nslices - 1, g.nslices, false, 0.f, 0.0));
+    NBC(launch_combine(L, r0, cnt, false, false, true, 0.f, 0.0));
+  }
+  return sync_all();
+}
+
+int step_impl(float dt, double dt64, int nsteps) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (nsteps < 0) return NBODY_ERR_ARG;
+  NBC(reconfigure());
+  for (int s = 0; s < nsteps; ++s) NBC(enqueue_step(dt, dt64));
+  return NBODY_OK;
+}
+
+int body_force_impl(void* pos, void* vel, float dt, double dt64, int n) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (n != g.n) return NBODY_ERR_ARG;
+  NBC(upload_impl(pos, vel));
+  NBC(reconfigure());
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    NBC(launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, false, dt, dt64));
+    NBC(launch_combine(L, 0, L.n_local, true, false, true, dt, dt64));
+  }
+  NBC(sync_all());
+  // vel back (pos is read-only for bodyForce)
+  const size_t wb = word_bytes();
+  if (g.multiprocess && g.nranks > 1) {
+    Local& L = g.loc[0];
+    NBC(gather_vel_multiprocess(L));
+    HIPC(hipMemcpy(vel, L.vel_full, (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+  }
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipMemcpy((char*)vel + (size_t)L.first * wb, L.vel, (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
+  }
+  return NBODY_OK;
+}
+
+int integrate_impl(void* pos, const void* vel, float dt, double dt64, int n) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (n != g.n) return NBODY_ERR_ARG;
+  NBC(upload_impl(pos, vel));
+  const size_t wb = word_bytes();
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    dim3 grid((L.n_local + kBlock - 1) / kBlock);
+    if (L.n_local > 0) {
+      if (g.fp64) hipLaunchKernelGGL((drift_kernel<double, d4>), grid, dim3(kBlock), 0, L.compute, (d4*)word_ptr(L.pos[L.cur], L.first), (const d4*)L.vel, L.n_local, dt, dt64);
+      else hipLaunchKernelGGL((drift_kernel<float, f4>), grid, dim3(kBlock), 0, L.compute, (f4*)word_ptr(L.pos[L.cur], L.first), (const f4*)L.vel, L.n_local, dt, dt64);
+      HIPC(hipGetLastError());
+    }
+    HIPC(hipEventRecord(L.ev_own_ready, L.compute));
+    L.all_present = (g.nranks == 1);
+  }
+  NBC(sync_all());
+  if (g.multiprocess && g.nranks > 1) {
+    NBC(complete_positions());
+    Local& L = g.loc[0];
+    HIPC(hipMemcpy(pos, L.pos[L.cur], (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+  }
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipMemcpy((char*)pos + (size_t)L.first * wb, word_ptr(L.pos[L.cur], L.first), (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
+  }
+  // the other locals' copies of pos are now stale: refresh lazily
+  for (int l = 0; l < g.nlocal; ++l) g.loc[l].all_present = (g.nranks == 1);
+  return NBODY_OK;
+}
+
+int forces_impl(const void* pos_words, void* force_words, int n) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (n != g.n || !pos_words || !force_words) return NBODY_ERR_ARG;
+  const size_t wb = word_bytes();
+  NBC(sync_all());
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipMemcpyAsync(L.pos[L.cur], pos_words, (size_t)g.n * wb, hipMemcpyHostToDevice, L.compute));
+    L.all_present = true;
+  }
+  NBC(forces_on_device(0, -1));
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipMemcpy((char*)force_words + (size_t)L.first * wb, L.force, (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
+  }
+  if (g.multiprocess && g.nranks > 1) return NBODY_ERR_UNSUPPORTED;  // force words of other ranks are not gathered
+  return NBODY_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+extern "C" {
+
+int nbody_init(int n, int ngpus, int fp64, int tile) {
+  if (g.init) nbody_shutdown();
+  if (ngpus <= 0 || ngpus > kMaxLocal) return NBODY_ERR_ARG;
+  NBC(init_common(n, fp64, tile));
+  int ndev = 0;
+  NBC(device_count(&ndev));
+  // NBODY_OVERSUBSCRIBE=1 lets several virtual ranks share a device (bring-up of the multi-GPU
+  // schedule on a one-GPU box; the data path is identical apart from the copies staying on-device).
+  const char* ov = getenv("NBODY_OVERSUBSCRIBE");
+  if (ngpus > ndev && !(ov && atoi(ov))) return NBODY_ERR_NO_DEVICE;
+  if (n < ngpus) return NBODY_ERR_ARG;
+  g.nranks = ngpus; g.nlocal = ngpus; g.multiprocess = false;
+  hipDeviceProp_t prop;
+  for (int r = 0; r < ngpus; ++r) {
+    Local& L = g.loc[r];
+    L = Local();
+    L.rank = r;
+    L.device = ngpus == 1 ? pick_device(0, ndev) : r % ndev;
+    L.first = slice_first(r, n, ngpus);
+    L.n_local = slice_first(r + 1, n, ngpus) - L.first;
+    int e = alloc_local(L);
+    if (e) { nbody_shutdown(); return e; }
+  }
+  HIPC(hipGetDeviceProperties(&prop, g.loc[0].device));
+  g.cu_count = prop.multiProcessorCount; g.clock_khz = prop.clockRate;
+  if (ngpus > 1) {
+    for (int a = 0; a < ngpus; ++a)
+      for (int b = 0; b < ngpus; ++b) {
+        if (g.loc[a].device == g.loc[b].device) continue;
+        (void)hipSetDevice(g.loc[a].device);
+        hipError_t e = hipDeviceEnablePeerAccess(g.loc[b].device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); }
+      }
+  }
+  g.init = true;
+  g.opt = Options();
+  int e = reconfigure();
+  if (e) { nbody_shutdown(); return e; }
+  return NBODY_OK;
+}
+
+int nbody_unique_id(void* uid128) {
+  if (!uid128) return NBODY_ERR_ARG;
+  NBC(rccl_load());
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCLC(g_rccl.GetUniqueId(&id));
+  memcpy(uid128, &id, sizeof(id));
+  return NBODY_OK;
+}
+
+int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void* uid128) {
+  if (g.init) nbody_shutdown();
+  if (nranks <= 0 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return NBODY_ERR_ARG;
+  if (nranks > 1 && !uid128) return NBODY_ERR_ARG;
+  NBC(init_common(n, fp64, tile));
+  if (n < nranks) return NBODY_ERR_ARG;
+  int ndev = 0;
+  NBC(device_count(&ndev));
+  g.nranks = nranks; g.nlocal = 1; g.multiprocess = true;
+  Local& L = g.loc[0];
+  L = Local();
+  L.rank = rank;
+  L.device = pick_device(rank, ndev);
+  L.first = slice_first(rank, n, nranks);
+  L.n_local = slice_first(rank + 1, n, nranks) - L.first;
+  int e = alloc_local(L);
+  if (e) { nbody_shutdown(); return e; }
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, L.device));
+  g.cu_count = prop.multiProcessorCount; g.clock_khz = prop.clockRate;
+  if (nranks > 1) {
+    e = rccl_load();
+    if (e) { nbody_shutdown(); return e; }
+    ncclUniqueId id;
+    memcpy(&id, uid128, sizeof(id));
+    HIPC(hipSetDevice(L.device));
+    ncclResult_t r = g_rccl.CommInitRank(&L.comm_h, nranks, id, rank);
+    if (r != ncclSuccess) { nbody_shutdown(); return 2000 + (int)r; }
+  }
+  g.init = true;
+  g.opt = Options();
+  e = reconfigure();
+  if (e) { nbody_shutdown(); return e; }
+  return NBODY_OK;
+}
+
+void nbody_shutdown(void) {
+  for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);
+  g.init = false; g.nlocal = 0; g.nranks = 1; g.partial_words = 0;
+}
+
+int nbody_set_option(int key, int value) {
+  switch (key) {
+    case NBODY_OPT_VARIANT: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.variant = value; break;
+    case NBODY_OPT_IBLOCK: if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NBODY_ERR_ARG; g.opt.iblock = value; break;
+    case NBODY_OPT_JSUB: if (value < 0 || value > 256) return NBODY_ERR_ARG; g.opt.jsub = value; break;
+    case NBODY_OPT_JSLICES: if (value < 0 || value > kMaxRanks) return NBODY_ERR_ARG; g.opt.jslices = value; break;
+    case NBODY_OPT_ARITH: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.arith = value; break;
+    case NBODY_OPT_SUM_ORDER: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.sum_order = value; break;
+    case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
+    case NBODY_OPT_COMM: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.comm = value; break;
+    case NBODY_OPT_OVERLAP: g.opt.overlap = value ? 1 : 0; break;
+    default: return NBODY_ERR_ARG;
+  }
+  if (g.init) { NBC(sync_all()); return reconfigure(); }
+  return NBODY_OK;
+}
+
+int nbody_get_info(int key, long long* value) {
+  if (!value) return NBODY_ERR_ARG;
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  const Local& L = g.loc[0];
+  switch (key) {
+    case NBODY_INFO_N: *value = g.n; break;
+    case NBODY_INFO_N_LOCAL: *value = L.n_local; break;
+    case NBODY_INFO_FIRST_BODY: *value = L.first; break;
+    case NBODY_INFO_RANK: *value = L.rank; break;
+    case NBODY_INFO_NRANKS: *value = g.nranks; break;
+    case NBODY_INFO_VARIANT: *value = g.variant; break;
+    case NBODY_INFO_IBLOCK: *value = g.R; break;
+    case NBODY_INFO_JSUB: *value = g.sub; break;
+    case NBODY_INFO_NSEG: *value = g.nseg; break;
+    case NBODY_INFO_DEVICE: *value = L.device; break;
+    case NBODY_INFO_CU_COUNT: *value = g.cu_count; break;
+    case NBODY_INFO_CLOCK_KHZ: *value = g.clock_khz; break;
+    case NBODY_INFO_FP64: *value = g.fp64; break;
+    case NBODY_INFO_TILE: *value = g.tile; break;
+    case NBODY_INFO_STEPS_DONE: *value = g.steps_done; break;
+    default: return NBODY_ERR_ARG;
+  }
+  return NBODY_OK;
+}
+
+const char* nbody_error_string(int code) {
+  static char buf[160];
+  switch (code) {
+    case NBODY_OK: return "ok";
+    case NBODY_ERR_NOT_INIT: return "nbody: not initialised";
+    case NBODY_ERR_ARG: return "nbody: bad argument";
+    case NBODY_ERR_NO_DEVICE: return "nbody: no usable HIP device (this library has no CPU path)";
+    case NBODY_ERR_RCCL_LOAD: return "nbody: could not load librccl.so.1";
+    case NBODY_ERR_STATE: return "nbody: wrong state for this call";
+    case NBODY_ERR_UNSUPPORTED: return "nbody: not supported in this configuration";
+    default: break;
+  }
+  if (code > 0 && code < 1000) { snprintf(buf, sizeof(buf), "HIP error %d (%s) near nbody_hip.hip:%d", code, hipGetErrorString((hipError_t)code), g_last_line); return buf; }
+  if (code >= 2000) { snprintf(buf, sizeof(buf), "RCCL error %d near nbody_hip.hip:%d", code - 2000, g_last_line); return buf; }
+  snprintf(buf, sizeof(buf), "nbody: unknown error %d", code);
+  return buf;
+}
+
+int nbody_upload(const BodySystem* host) { if (!host) return NBODY_ERR_ARG; if (g.init && g.fp64) return NBODY_ERR_STATE; return upload_impl(host->pos, host->vel); }
+int nbody_download(BodySystem* host) { if (!host) return NBODY_ERR_ARG; if (g.init && g.fp64) return NBODY_ERR_STATE; return download_impl(host->pos, host->vel); }
+int nbody_upload_d(const BodySystemD* host) { if (!host) return NBODY_ERR_ARG; if (g.init && !g.fp64) return NBODY_ERR_STATE; return upload_impl(host->pos, host->vel); }
+int nbody_download_d(BodySystemD* host) { if (!host) return NBODY_ERR_ARG; if (g.init && !g.fp64) return NBODY_ERR_STATE; return download_impl(host->pos, host->vel); }
+
+int bodyForce(float* pos, float* vel, float dt, int n) { if (g.init && g.fp64) return NBODY_ERR_STATE; return body_force_impl(pos, vel, dt, (double)dt, n); }
+int integrate(float* pos, const float* vel, float dt, int n) { if (g.init && g.fp64) return NBODY_ERR_STATE; return integrate_impl(pos, vel, dt, (double)dt, n); }
+int bodyForce_d(double* pos, double* vel, double dt, int n) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return body_force_impl(pos, vel, (float)dt, dt, n); }
+int integrate_d(double* pos, const double* vel, double dt, int n) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return integrate_impl(pos, vel, (float)dt, dt, n); }
+
+int nbody_step(float dt, int nsteps) { if (g.init && g.fp64) return NBODY_ERR_STATE; return step_impl(dt, (double)dt, nsteps); }
+int nbody_step_d(double dt, int nsteps) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return step_impl((float)dt, dt, nsteps); }
+int nbody_sync(void) { if (!g.init) return NBODY_ERR_NOT_INIT; return sync_all(); }
+
+int nbody_forces(const float* pos_words, float* force_words, int n) { if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
+int nbody_forces_d(const double* pos_words, double* force_words, int n) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
+
+int nbody_forces_rows(int first_row, int n_rows, float* force_words) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (g.fp64 || g.nlocal != 1 || !force_words) return NBODY_ERR_UNSUPPORTED;
+  Local& L = g.loc[0];
+  if (first_row < 0 || n_rows <= 0 || first_row + n_rows > L.n_local) return NBODY_ERR_ARG;
+  NBC(forces_on_device(first_row, n_rows));
+  HIPC(hipSetDevice(L.device));
+  HIPC(hipMemcpy(force_words, word_ptr(L.force, first_row), (size_t)n_rows * word_bytes(), hipMemcpyDeviceToHost));
+  return NBODY_OK;
+}
+
+int nbody_mailbox_run(void* ram_a, void* ram_b, int clock_khz) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (g.fp64 || !ram_a || !ram_b) return NBODY_ERR_ARG;
+  // word 0: bit 0 BEGIN, bits [46:32] NUM_PTS                         S/top_level.vhd:184-185
+  uint32_t* w0 = (uint32_t*)ram_a;
+  if (!(w0[0] & 1u)) return NBODY_ERR_STATE;
+  const int num_pts = (int)(w0[1] & 0x7FFFu);
+  if (num_pts != g.n) return NBODY_ERR_ARG;
+  hipEvent_t e0, e1;
+  HIPC(hipSetDevice(g.loc[0].device));
+  HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+  HIPC(hipEventRecord(e0, g.loc[0].compute));
+  // bodies are words 1..N                                              S/top_level.vhd:55, 206-208
+  int rc = forces_impl((const float*)ram_a + 4, (float*)ram_b, num_pts);
+  HIPC(hipEventRecord(e1, g.loc[0].compute));
+  HIPC(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  HIPC(hipEventDestroy(e0)); HIPC(hipEventDestroy(e1));
+  if (rc) return rc;
+  // completion: word 0 <- {ticks in [63:32], 0 elsewhere}: BEGIN reads 0  S/top_level.vhd:146, 255-263
+  // one tick = 1000 clocks (S/top_level.vhd:121-144); the counter starts at 1 on BEGIN's rising edge (:138-139)
+  const double khz = clock_khz > 0 ? (double)clock_khz : 300000.0;
+  uint32_t ticks = 1u + (uint32_t)((double)ms * khz / 1000.0);
+  w0[0] = 0; w0[1] = ticks; w0[2] = 0; w0[3] = 0;
+  return NBODY_OK;
+}
+
+int nbody_kernel_time(double* ms_total, long long* launches, int reset) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  double ms = 0.0; long long n = 0;
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    NBC(timer_drain(L, 0));
+    ms = std::max(ms, L.t_ms);   // locals run concurrently: report the slowest device
+    n += L.t_launches;
+    if (reset) { L.t_ms = 0.0; L.t_launches = 0; }
+  }
+  if (ms_total) *ms_total = ms;
+  if (launches) *launches = n;
+  return NBODY_OK;
+}
+
+int nbody_device_ptr(int which, void** ptr, size_t* bytes) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!ptr) return NBODY_ERR_ARG;
+  Local& L = g.loc[0];
+  const size_t wb = word_bytes();
+  switch (which) {
+    case 0: *ptr = L.pos[L.cur]; if (bytes) *bytes = (size_t)g.n * wb; break;
+    case 1: *ptr = L.vel; if (bytes) *bytes = (size_t)L.n_local * wb; break;
+    case 2: *ptr = L.force; if (bytes) *bytes = (size_t)L.n_local * wb; break;
+    default: return NBODY_ERR_ARG;
+  }
+  return NBODY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""Host-side mirror of the path's interface: bodyForce()/integrate() on a
+{pos, vel} structure of arrays, the device-resident step loop and the
+force-only (mailbox) entry point — thin Python over the C-ABI of
+include/nbody.h.  All compute happens in libnbody_hip.so (HIP, gfx950).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _as(a, dtype):
+    a = np.ascontiguousarray(a, dtype)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("expected an (n, 4) array of %s words" % np.dtype(dtype).name)
+    return a
+
+
+class NBody:
+    """One context per process (the reference handles one request at a time, S/top_level.vhd:180-186)."""
+
+    def __init__(self, n, fp64=False, tile=0, ngpus=1, rank=None, nranks=None, uid=None):
+        self.lib = L.load()
+        self.n, self.fp64 = int(n), bool(fp64)
+        self.dtype = np.float64 if fp64 else np.float32
+        if rank is None:
+            L.check(self.lib.nbody_init(self.n, int(ngpus), int(self.fp64), int(tile)))
+        else:
+            buf = C.create_string_buffer(bytes(uid), 128) if uid is not None else None
+            L.check(self.lib.nbody_init_rank(self.n, int(self.fp64), int(tile), int(rank), int(nranks), buf))
+        self._open = True
+
+    # ---- options / info ----
+    def set_option(self, key, value):
+        L.check(self.lib.nbody_set_option(int(key), int(value)))
+
+    def info(self, key):
+        v = C.c_longlong()
+        L.check(self.lib.nbody_get_info(int(key), C.byref(v)))
+        return v.value
+
+    @property
+    def config(self):
+        names = {L.VARIANT_SMEM: "smem", L.VARIANT_LDS: "lds", L.VARIANT_READLANE: "readlane"}
+        return dict(variant=names.get(self.info(L.INFO_VARIANT), "?"), iblock=self.info(L.INFO_IBLOCK),
+                    jsub=self.info(L.INFO_JSUB), nseg=self.info(L.INFO_NSEG), tile=self.info(L.INFO_TILE),
+                    n_local=self.info(L.INFO_N_LOCAL), first_body=self.info(L.INFO_FIRST_BODY),
+                    rank=self.info(L.INFO_RANK), nranks=self.info(L.INFO_NRANKS))
+
+    # ---- state ----
+    def _bs(self, pos, vel):
+        if self.fp64:
+            return L.BodySystemD(pos.ctypes.data_as(C.POINTER(C.c_double)), vel.ctypes.data_as(C.POINTER(C.c_double)))
+        return L.BodySystem(pos.ctypes.data_as(C.POINTER(C.c_float)), vel.ctypes.data_as(C.POINTER(C.c_float)))
+
+    def upload(self, pos, vel):
+        pos, vel = _as(pos, self.dtype), _as(vel, self.dtype)
+        if len(pos) != self.n or len(vel) != self.n:
+            raise ValueError("upload expects the full %d bodies" % self.n)
+        bs = self._bs(pos, vel)
+        L.check((self.lib.nbody_upload_d if self.fp64 else self.lib.nbody_upload)(C.byref(bs)))
+
+    def download(self):
+        pos = np.empty((self.n, 4), self.dtype)
+        vel = np.empty((self.n, 4), self.dtype)
+        bs = self._bs(pos, vel)
+        L.check((self.lib.nbody_download_d if self.fp64 else self.lib.nbody_download)(C.byref(bs)))
+        return pos, vel
+
+    # ---- the path: same names and argument meaning as the C entry points ----
+    def bodyForce(self, pos, vel, dt):
+        """v += dt * F(pos), in place on vel; pos is read-only."""
+        p, v = _as(pos, self.dtype), _as(vel, self.dtype)
+        ct = C.c_double if self.fp64 else C.c_float
+        fn = self.lib.bodyForce_d if self.fp64 else self.lib.bodyForce
+        L.check(fn(p.ctypes.data_as(C.POINTER(ct)), v.ctypes.data_as(C.POINTER(ct)), dt, len(p)))
+        if v is not vel:
+            vel[...] = v
+        return vel
+
+    def integrate(self, pos, vel, dt):
+        """r += v * dt, in place on pos."""
+        p, v = _as(pos, self.dtype), _as(vel, self.dtype)
+        ct = C.c_double if self.fp64 else C.c_float
+        fn = self.lib.integrate_d if self.fp64 else self.lib.integrate
+        L.check(fn(p.ctypes.data_as(C.POINTER(ct)), v.ctypes.data_as(C.POINTER(ct)), dt, len(p)))
+        if p is not pos:
+            pos[...] = p
+        return pos
+
+    def step(self, dt, nsteps=1):
+        """nsteps x {bodyForce; integrate} on the uploaded state; asynchronous."""
+        L.check((self.lib.nbody_step_d if self.fp64 else self.lib.nbody_step)(dt, int(nsteps)))
+
+    def sync(self):
+        L.check(self.lib.nbody_sync())
+
+    def forces(self, pos):
+        """{Fx, Fy, Fz, 0} per body from {x, y, z, .} words (the reference's RAM images)."""
+        p = _as(pos, self.dtype)
+        out = np.empty_like(p)
+        ct = C.c_double if self.fp64 else C.c_float
+        fn = self.lib.nbody_forces_d if self.fp64 else self.lib.nbody_forces
+        L.check(fn(p.ctypes.data_as(C.POINTER(ct)), out.ctypes.data_as(C.POINTER(ct)), len(p)))
+        return out
+
+    def forces_rows(self, first_row, n_rows):
+        """Forces on a row sample from the state on the device (fp32, one GPU)."""
+        out = np.empty((n_rows, 4), np.float32)
+        L.check(self.lib.nbody_forces_rows(int(first_row), int(n_rows), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def kernel_time(self, reset=False):
+        ms, cnt = C.c_double(), C.c_longlong()
+        L.check(self.lib.nbody_kernel_time(C.byref(ms), C.byref(cnt), int(reset)))
+        return ms.value, cnt.value
+
+    def device_ptr(self, which):
+        p, b = C.c_void_p(), C.c_size_t()
+        L.check(self.lib.nbody_device_ptr(int(which), C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def close(self):
+        if self._open:
+            self.lib.nbody_shutdown()
+            self._open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def unique_id():
+    buf = C.create_string_buffer(128)
+    L.check(L.load().nbody_unique_id(buf))
+    return bytes(buf.raw)

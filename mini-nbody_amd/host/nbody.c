@@ -1,0 +1,113 @@
+/* nbody.c — the host program, in C, over the C-ABI of include/nbody.h
+ * (north_star: "host code stays in C ... calling hand-written HIP kernels
+ * through a thin C-ABI shim").  The reference tree holds no host program
+ * (SURVEY.md §0); this is the build's own: deterministic initial conditions,
+ * the bodyForce()/integrate() loop or the device-resident step loop, timing
+ * with the first iteration excluded as warm-up, and the metric of BASELINE.md
+ * §2: billion pair-interactions/s = N^2 * timed_steps / seconds / 1e9.
+ *
+ * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict]
+ */
+#define _POSIX_C_SOURCE 199309L
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "nbody.h"
+#include "nbody_ic.h"
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+#define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s failed: %s\n", #call, nbody_error_string(rc_)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0;
+  unsigned long long seed = NBODY_IC_DEFAULT_SEED;
+  for (int a = 1; a < argc; ++a) {
+    if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--tile") && a + 1 < argc) tile = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--seed") && a + 1 < argc) seed = strtoull(argv[++a], NULL, 10);
+    else if (!strcmp(argv[a], "--fp64")) fp64 = 1;
+    else if (!strcmp(argv[a], "--host-loop")) host_loop = 1;
+    else if (!strcmp(argv[a], "--strict")) strict = 1;
+    else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
+    else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict]\n", argv[0]); return 2; }
+  }
+  if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
+  const float dt = 0.01f;
+  const size_t words = (size_t)n * 4;
+  CHECK(nbody_init(n, gpus, fp64, tile));
+  if (strict) CHECK(nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_STRICT));
+
+  double total = 0.0;
+  if (!fp64) {
+    float *buf = (float *)malloc(2 * words * sizeof(float));
+    if (!buf) return 3;
+    BodySystem p = { buf, buf + words };
+    nbody_ic_fill_f32(p.pos, p.vel, (size_t)n, 0, (size_t)n, seed);
+    if (host_loop) {
+      for (int it = 1; it <= iters; ++it) {
+        double t0 = now_s();
+        CHECK(bodyForce(p.pos, p.vel, dt, n));   /* compute interbody forces, kick */
+        CHECK(integrate(p.pos, p.vel, dt, n));   /* drift */
+        double t = now_s() - t0;
+        if (it > 1) total += t;                  /* first iteration is warm-up */
+      }
+    } else {
+      CHECK(nbody_upload(&p));
+      CHECK(nbody_step(dt, 1));
+      CHECK(nbody_sync());
+      double t0 = now_s();
+      CHECK(nbody_step(dt, iters - 1));
+      CHECK(nbody_sync());
+      total = now_s() - t0;
+      CHECK(nbody_download(&p));
+    }
+    double cx = 0, cy = 0, cz = 0;
+    for (int i = 0; i < n; ++i) { cx += p.pos[4 * i]; cy += p.pos[4 * i + 1]; cz += p.pos[4 * i + 2]; }
+    printf("checksum (sum of positions): %.9g %.9g %.9g\n", cx, cy, cz);
+    free(buf);
+  } else {
+    double *buf = (double *)malloc(2 * words * sizeof(double));
+    if (!buf) return 3;
+    BodySystemD p = { buf, buf + words };
+    nbody_ic_fill_f64(p.pos, p.vel, (size_t)n, 0, (size_t)n, seed);
+    if (host_loop) {
+      for (int it = 1; it <= iters; ++it) {
+        double t0 = now_s();
+        CHECK(bodyForce_d(p.pos, p.vel, dt, n));
+        CHECK(integrate_d(p.pos, p.vel, dt, n));
+        double t = now_s() - t0;
+        if (it > 1) total += t;
+      }
+    } else {
+      CHECK(nbody_upload_d(&p));
+      CHECK(nbody_step_d(dt, 1));
+      CHECK(nbody_sync());
+      double t0 = now_s();
+      CHECK(nbody_step_d(dt, iters - 1));
+      CHECK(nbody_sync());
+      total = now_s() - t0;
+      CHECK(nbody_download_d(&p));
+    }
+    double cx = 0, cy = 0, cz = 0;
+    for (int i = 0; i < n; ++i) { cx += p.pos[4 * i]; cy += p.pos[4 * i + 1]; cz += p.pos[4 * i + 2]; }
+    printf("checksum (sum of positions): %.17g %.17g %.17g\n", cx, cy, cz);
+    free(buf);
+  }
+  double avg = total / (double)(iters - 1);
+  long long info_r = 0, info_s = 0;
+  nbody_get_info(NBODY_INFO_IBLOCK, &info_r);
+  nbody_get_info(NBODY_INFO_NSEG, &info_s);
+  printf("%d Bodies (%s, %d GPU%s, %s loop, %lld bodies/lane, %lld segments): average %0.3f Billion Interactions / second (%.3f ms / step)\n",
+         n, fp64 ? "fp64" : "fp32", gpus, gpus > 1 ? "s" : "", host_loop ? "host" : "device", info_r, info_s,
+         1e-9 * (double)n * (double)n / avg, 1e3 * avg);
+  nbody_shutdown();
+  return 0;
+}

@@ -1,0 +1,376 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
+
+Two bars, both written out here:
+  * STRICT arithmetic (NBODY_ARITH_STRICT / _REFERENCE_STRICT): every operation is
+    IEEE-exact, so the GPU must equal the oracle BIT FOR BIT — forces, and
+    positions/velocities after any number of steps, for every delivery variant,
+    register blocking and segmentation.
+  * FAST arithmetic (v_rsq_f32, <= 1 ulp; the timed mode): the north_star's 1e-5
+    relative fp32 tolerance on single-pass forces (max-norm), and on positions after
+    the fixed step count in max-norm and in the median; element-wise it is compared
+    with the spread two CPU restatements show when their 1/sqrt differs by 1 ulp
+    (the dynamics with eps = 1e-9 amplify any last-bit difference — see DESIGN.md
+    "Parity").
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: "within 1e-5 relative fp32 tolerance"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def maxnorm_rel(a, b):
+    return float(np.abs(a[:, :3].astype(np.float64) - b[:, :3]).max() / np.abs(b[:, :3]).max())
+
+
+@pytest.fixture()
+def engine_factory(nb):
+    made = []
+
+    def make(n, **kw):
+        for e in made:
+            e.close()
+        e = nb.NBody(n, **kw)
+        made.append(e)
+        return e
+
+    yield make
+    for e in made:
+        e.close()
+
+
+VARIANTS = ["smem", "lds", "readlane"]
+
+
+def set_variant(nb, eng, variant, iblock, jsub=1, jslices=1, arith=None, tile=None):
+    eng.set_option(nb.OPT_VARIANT, {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE}[variant])
+    eng.set_option(nb.OPT_IBLOCK, iblock)
+    eng.set_option(nb.OPT_JSUB, jsub)
+    eng.set_option(nb.OPT_JSLICES, jslices)
+    if arith is not None:
+        eng.set_option(nb.OPT_ARITH, arith)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 257, 1000, 2085])
+def test_strict_forces_bit_exact_ragged_sizes(nb, oracle_fast, engine_factory, n):
+    pos, _ = nb.make_bodies(n, seed=n + 1)
+    want = oracle_fast.forces_f32(pos, d2=O.D2_FMA3, rsqrt=O.RSQRT_F64)
+    eng = engine_factory(n)
+    for variant in VARIANTS:
+        for iblock in (1, 4):
+            set_variant(nb, eng, variant, iblock, arith=nb.ARITH_STRICT)
+            got = eng.forces(pos)
+            assert np.array_equal(bits(got), bits(want)), (variant, iblock)
+    set_variant(nb, eng, "smem", 2, arith=nb.ARITH_REFERENCE_STRICT)
+    want_ref = oracle_fast.forces_f32(pos, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64)
+    assert np.array_equal(bits(eng.forces(pos)), bits(want_ref))
+
+
+@pytest.mark.parametrize("tile", [256, 512, 1024])
+def test_strict_lds_tiles(nb, oracle_fast, engine_factory, tile):
+    n = 3000
+    pos, _ = nb.make_bodies(n, seed=5)
+    want = oracle_fast.forces_f32(pos)
+    eng = engine_factory(n, tile=tile)
+    set_variant(nb, eng, "lds", 2, arith=nb.ARITH_STRICT)
+    assert np.array_equal(bits(eng.forces(pos)), bits(want))
+
+
+def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engine_factory):
+    """All delivery variants and register blockings run the same operations in the same order."""
+    n = 4096 + 37
+    pos, _ = nb.make_bodies(n, seed=11)
+    eng = engine_factory(n)
+    ref = None
+    for variant in VARIANTS:
+        for iblock in (1, 2, 4):
+            set_variant(nb, eng, variant, iblock, arith=nb.ARITH_FMA3)
+            got = eng.forces(pos)
+            if ref is None:
+                ref = got
+            assert np.array_equal(bits(got), bits(ref)), (variant, iblock)
+    set_variant(nb, eng, "smem", 8, arith=nb.ARITH_FMA3)
+    assert np.array_equal(bits(eng.forces(pos)), bits(ref))
+    want = oracle_fast.forces_f32(pos)
+    f64 = oracle_fast.forces_f64_from_f32(pos)
+    assert maxnorm_rel(ref, want) < TOL
+    # against the fp64 arbiter the GPU is as good as the CPU fp32 path
+    assert maxnorm_rel(ref, f64) < max(2 * maxnorm_rel(want, f64), 2e-6)
+    assert np.all(ref[:, 3] == 0)   # S/compute_store.vhd:242: the 4th word is 0
+
+
+def test_segmentation_matches_host_mirror_bitwise(nb, oracle_fast, engine_factory):
+    """jslices x jsub segments combined in ascending order == the Python mirror of the decomposition
+    (mini-nbody_amd/sharding.py) driven by the oracle, bit for bit in strict mode."""
+    n = 5000
+    pos, _ = nb.make_bodies(n, seed=3)
+    eng = engine_factory(n)
+    for nsl, sub in ((1, 4), (3, 1), (8, 2), (7, 3)):
+        set_variant(nb, eng, "smem", 4, jsub=sub, jslices=nsl, arith=nb.ARITH_STRICT)
+        assert eng.config["nseg"] == nsl * sub
+        got = eng.forces(pos)
+        parts = []
+        for q in range(nsl):
+            for t in range(sub):
+                b, e = nb.sharding.segment_bounds(q, t, n, nsl, sub)
+                parts.append(oracle_fast.forces_f32(pos, pos[b:e]))
+        want = nb.sharding.combine_ascending(parts)
+        assert np.array_equal(bits(got), bits(want)), (nsl, sub)
+
+
+def test_fpga16_order(nb, oracle_fast, engine_factory):
+    """16 strided partials + pairwise tree, S/fxyz.vhd:129-184, S/final_adder.vhd:88-104."""
+    for n in (5, 16, 100, 1031):
+        pos, _ = nb.make_bodies(n, seed=2)
+        eng = engine_factory(n)
+        eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_FPGA16)
+        eng.set_option(nb.OPT_JSUB, 1)
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_REFERENCE_STRICT)
+        want = oracle_fast.forces_f32(pos, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
+        assert np.array_equal(bits(eng.forces(pos)), bits(want)), n
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
+        assert maxnorm_rel(eng.forces(pos), want) < TOL
+
+
+def test_bodyForce_integrate_config1_shape(nb, oracle_fast, engine_factory):
+    """BASELINE config 1's shape (N = 4096, 10 iterations) through the host-pointer entry points."""
+    n, dt, iters = 4096, 0.01, 10
+    pos, vel = nb.make_bodies(n)
+    opos, ovel = pos.copy(), vel.copy()
+    eng = engine_factory(n)
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    for _ in range(iters):
+        eng.bodyForce(pos, vel, dt)
+        eng.integrate(pos, vel, dt)
+        oracle_fast.bodyForce(opos, ovel, dt)
+        oracle_fast.integrate(opos, ovel, dt)
+    assert np.array_equal(bits(pos), bits(opos))
+    assert np.array_equal(bits(vel), bits(ovel))
+
+
+@pytest.mark.parametrize("jsub", [1, 4])
+def test_step_loop_strict_bit_exact(nb, oracle_fast, engine_factory, jsub):
+    n, dt, steps = 4096, 0.01, 10
+    pos, vel = nb.make_bodies(n)
+    eng = engine_factory(n)
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    eng.set_option(nb.OPT_JSUB, jsub)
+    eng.upload(pos, vel)
+    eng.step(dt, steps)
+    gp, gv = eng.download()
+    if jsub == 1:
+        op, ov = pos.copy(), vel.copy()
+        oracle_fast.step(op, ov, dt, steps)
+    else:
+        op, ov = pos.copy(), vel.copy()
+        dtf = np.float32(dt)
+        for _ in range(steps):
+            parts = []
+            for t in range(jsub):
+                b, e = nb.sharding.segment_bounds(0, t, n, 1, jsub)
+                parts.append(oracle_fast.forces_f32(op, op[b:e]))
+            acc = nb.sharding.combine_ascending(parts)
+            # kick and drift with one rounding each (fma): emulate in float64, exact for fp32 inputs
+            ov[:, :3] = (dtf.astype(np.float64) * acc[:, :3].astype(np.float64) + ov[:, :3]).astype(np.float32)
+            op[:, :3] = (ov[:, :3].astype(np.float64) * dtf.astype(np.float64) + op[:, :3]).astype(np.float32)
+    assert np.array_equal(bits(gp), bits(op))
+    assert np.array_equal(bits(gv), bits(ov))
+    assert np.all(gp[:, 3] == 1) and np.all(gv[:, 3] == 0)
+
+
+def test_step_loop_fast_within_tolerance(nb, oracle_fast, engine_factory):
+    """The timed mode (v_rsq_f32) after the fixed step count, N = 4096, 10 steps."""
+    n, dt, steps = 4096, 0.01, 10
+    pos, vel = nb.make_bodies(n)
+    eng = engine_factory(n)
+    eng.upload(pos, vel)
+    eng.step(dt, 1)
+    g1, _ = eng.download()
+    eng.step(dt, steps - 1)
+    gp, gv = eng.download()
+    o1, ov1 = pos.copy(), vel.copy()
+    oracle_fast.step(o1, ov1, dt, 1)
+    op, ov = pos.copy(), vel.copy()
+    oracle_fast.step(op, ov, dt, steps)
+    # a second CPU restatement whose 1/sqrt differs by <= 1 ulp: the envelope of "equally right" answers
+    ep, ev = pos.copy(), vel.copy()
+    oracle_fast.step(ep, ev, dt, steps, rsqrt=O.RSQRT_DIVSQRT)
+    # one step: no amplification yet -> plain tolerance
+    assert maxnorm_rel(g1, o1) < TOL
+    el1 = np.abs(g1[:, :3] - o1[:, :3]) / np.maximum(np.abs(o1[:, :3]), 1e-30)
+    assert np.quantile(el1, 0.999) < TOL
+    # fixed step count: median within tolerance, and no worse than the CPU-vs-CPU envelope
+    el = np.abs(gp[:, :3] - op[:, :3]) / np.maximum(np.abs(op[:, :3]), 1e-30)
+    env = np.abs(ep[:, :3] - op[:, :3]) / np.maximum(np.abs(op[:, :3]), 1e-30)
+    assert np.median(el) < TOL
+    assert np.isfinite(gp).all() and np.isfinite(gv).all()
+    assert maxnorm_rel(gp, op) < 4 * max(maxnorm_rel(ep, op), 1e-6)
+    assert np.quantile(el, 0.99) < 4 * max(np.quantile(env, 0.99), TOL)
+
+
+def test_config2_n65536(nb, oracle_fast, engine_factory):
+    """BASELINE config 2: N = 65536, LDS tile = 256 and the default SMEM variant.
+    Strict mode bit-exact over 3 steps (1.3e10 pairs on the host); 100 steps on the GPU stay finite
+    and agree between the two variants bit for bit."""
+    n, dt = 65536, 0.01
+    pos, vel = nb.make_bodies(n)
+    eng = engine_factory(n, tile=256)
+    op, ov = pos.copy(), vel.copy()
+    oracle_fast.step(op, ov, dt, 3)
+    for variant in ("lds", "smem"):
+        set_variant(nb, eng, variant, 4, jsub=1, arith=nb.ARITH_STRICT)
+        eng.upload(pos, vel)
+        eng.step(dt, 3)
+        gp, gv = eng.download()
+        assert np.array_equal(bits(gp), bits(op)), variant
+        assert np.array_equal(bits(gv), bits(ov)), variant
+    out = []
+    for variant in ("lds", "smem"):
+        set_variant(nb, eng, variant, 0, jsub=0, arith=nb.ARITH_FMA3)
+        eng.set_option(nb.OPT_JSUB, 8)
+        eng.upload(pos, vel)
+        eng.step(dt, 100)
+        out.append(eng.download())
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0]))
+    # fast-mode forces of the initial state against the oracle
+    eng.upload(pos, vel)
+    f = eng.forces(pos)
+    assert maxnorm_rel(f, oracle_fast.forces_f32(pos)) < TOL
+
+
+def test_headline_size_row_sample_and_properties(nb, oracle_fast, engine_factory):
+    """N = 1,048,576 (BASELINE config 3): one CPU pass is 1.1e12 pairs, so parity is row-sampled
+    (SURVEY.md §7 "Hard parts"): 1024 rows incl. the first and last body, all N sources, strict mode
+    bit-exact and fast mode within tolerance; plus size-independent properties on the full state."""
+    n = 1 << 20
+    pos, vel = nb.make_bodies(n)
+    eng = engine_factory(n)
+    eng.upload(pos, vel)
+    sample = [(0, 256), (n // 2 - 128, 256), (n - 512, 512)]
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    for first, cnt in sample:
+        got = eng.forces_rows(first, cnt)
+        want = oracle_fast.forces_f32(pos[first:first + cnt], pos)
+        assert np.array_equal(bits(got), bits(want)), first
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
+    for first, cnt in sample[:1]:
+        got = eng.forces_rows(first, cnt)
+        want = oracle_fast.forces_f32(pos[first:first + cnt], pos)
+        assert maxnorm_rel(got, want) < TOL
+    # properties: a step moves exactly r' = r + v'*dt (checked from the downloaded state), w carried
+    eng.step(0.01, 1)
+    p1, v1 = eng.download()
+    dt = np.float64(np.float32(0.01))
+    assert np.array_equal(bits(p1[:, :3]), bits((v1[:, :3].astype(np.float64) * dt + pos[:, :3]).astype(np.float32)))
+    assert np.all(p1[:, 3] == 1) and np.all(v1[:, 3] == 0) and np.isfinite(v1).all()
+    # momentum: unit masses and antisymmetric pair terms -> sum_i F_i ~ 0 relative to sum_i |F_i|
+    dv = (v1[:, :3].astype(np.float64) - vel[:, :3]) / dt
+    assert np.abs(dv.sum(0)).max() / np.abs(dv).sum() < 1e-4
+
+
+def test_translation_property(nb, engine_factory):
+    """Forces depend on differences only: shifting every body by a power-of-two-exact offset that
+    keeps all coordinates exactly representable leaves them bit-identical."""
+    n = 2048
+    pos, _ = nb.make_bodies(n, seed=9)
+    pos[:, :3] = np.round(pos[:, :3] * 1024) / 1024      # 11 fractional bits
+    eng = engine_factory(n)
+    f0 = eng.forces(pos)
+    shifted = pos.copy()
+    shifted[:, :3] += np.float32(8.0)
+    assert np.array_equal(bits(eng.forces(shifted)), bits(f0))
+
+
+def test_coincident_bodies_stay_finite(nb, engine_factory):
+    """S/dzsoft.vhd:177, 201-202: eps keeps d2 > 0 for coincident bodies; their mutual term is exactly 0."""
+    n = 512
+    pos, _ = nb.make_bodies(n, seed=4)
+    pos[1] = pos[0]
+    pos[100:110] = pos[99]
+    eng = engine_factory(n)
+    f = eng.forces(pos)
+    assert np.isfinite(f).all()
+    assert np.array_equal(bits(f[0]), bits(f[1]))
+
+
+def test_mailbox_front_end(nb, oracle_fast, engine_factory):
+    """The reference's RAM images verbatim."""
+    n = 1000
+    pos, _ = nb.make_bodies(n, seed=8)
+    pos[:, 3] = np.float32(123.0)                         # bits 127:96 are ignored, S/top_level.vhd:206-208
+    ram_a = nb.mailbox.encode_request(pos)
+    assert nb.mailbox.decode_control(ram_a) == dict(begin=1, num_pts=n, ticks=n)
+    eng = engine_factory(n)
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    ram_b = nb.mailbox.run(eng, ram_a, clock_khz=300000)
+    ctl = nb.mailbox.decode_control(ram_a)
+    assert ctl["begin"] == 0 and ctl["ticks"] >= 1       # S/top_level.vhd:146, 255-263
+    assert np.array_equal(bits(ram_b), bits(oracle_fast.forces_f32(pos)))
+    assert np.all(ram_b[:, 3] == 0)
+    with pytest.raises(nb.NBodyError):                    # BEGIN not set -> nothing to do
+        nb.mailbox.run(eng, ram_a)
+
+
+def test_fp64_path(nb, oracle_fast, engine_factory):
+    """BASELINE config 5's arithmetic at a size the host can check: fp64 forces and 5 steps."""
+    n = 4096
+    pos, vel = nb.make_bodies(n, dtype=np.float64)
+    eng = engine_factory(n, fp64=True)
+    f = eng.forces(pos)
+    want = oracle_fast.forces_f64(pos)
+    assert maxnorm_rel(f, want) < 1e-13
+    for iblock, jsub in ((1, 1), (2, 4), (4, 2)):
+        eng.set_option(nb.OPT_IBLOCK, iblock)
+        eng.set_option(nb.OPT_JSUB, jsub)
+        eng.upload(pos, vel)
+        eng.step(0.01, 5)
+        gp, gv = eng.download()
+        op, ov = pos.copy(), vel.copy()
+        oracle_fast.step(op, ov, 0.01, 5)
+        assert np.abs(gp[:, :3] - op[:, :3]).max() / np.abs(op[:, :3]).max() < 1e-10
+    p2, v2 = pos.copy(), vel.copy()
+    eng.bodyForce(p2, v2, 0.01)
+    eng.integrate(p2, v2, 0.01)
+    o2, ov2 = pos.copy(), vel.copy()
+    oracle_fast.bodyForce(o2, ov2, 0.01)
+    oracle_fast.integrate(o2, ov2, 0.01)
+    assert np.abs(p2 - o2).max() < 1e-12 * np.abs(o2).max()
+
+
+def test_virtual_multi_gpu_schedule_bitwise(nb, oracle_fast, engine_factory, monkeypatch):
+    """The multi-GPU schedule (i-sharding, ring-ordered arrival, per-slice partials, ascending combine,
+    double-buffered positions) with P virtual ranks sharing this box's one GPU; the transfers are peer
+    copies, everything else is the code the 8-GPU run executes.  Must equal one GPU configured with
+    the same segmentation bit for bit, in fast mode, over several steps."""
+    monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
+    n, dt, steps = 8192 + 5, 0.01, 4
+    pos, vel = nb.make_bodies(n, seed=21)
+    results = {}
+    for P in (1, 2, 3, 4):
+        for overlap in ((1,) if P == 1 else (1, 0)):
+            eng = engine_factory(n, ngpus=P)
+            eng.set_option(nb.OPT_IBLOCK, 2)
+            eng.set_option(nb.OPT_JSUB, 2)
+            eng.set_option(nb.OPT_OVERLAP, overlap)
+            eng.upload(pos, vel)
+            eng.step(dt, steps)
+            results[(P, overlap)] = eng.download()
+            # reference: one GPU, same segmentation
+            one = engine_factory(n)
+            one.set_option(nb.OPT_IBLOCK, 2)
+            one.set_option(nb.OPT_JSUB, 2)
+            one.set_option(nb.OPT_JSLICES, P)
+            one.upload(pos, vel)
+            one.step(dt, steps)
+            wp, wv = one.download()
+            gp, gv = results[(P, overlap)]
+            assert np.array_equal(bits(gp), bits(wp)), (P, overlap)
+            assert np.array_equal(bits(gv), bits(wv)), (P, overlap)

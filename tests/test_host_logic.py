@@ -1,0 +1,79 @@
+"""Host-side logic on CPU: the IC generator (numpy mirror == C header), the sharding arithmetic,
+the mailbox images."""
+import numpy as np
+import pytest
+
+
+def test_ic_numpy_matches_c(nb, oracle):
+    for n, seed in ((1, 42), (1000, 42), (4099, 7)):
+        p, v = oracle.ic(n, seed=seed)
+        p2, v2 = nb.make_bodies(n, seed=seed)
+        assert np.array_equal(p, p2) and np.array_equal(v, v2)
+        assert p.min() >= -1 and p[:, :3].max() < 1 and np.all(p[:, 3] == 1) and np.all(v[:, 3] == 0)
+    p, v = oracle.ic(5000)
+    p3, v3 = nb.make_bodies(5000, first=1234, count=99)
+    assert np.array_equal(p[1234:1333], p3) and np.array_equal(v[1234:1333], v3)
+    p64, _ = nb.make_bodies(100, dtype=np.float64)
+    assert np.array_equal(p64, oracle.ic(100, dtype=np.float64)[0])
+    assert np.array_equal(p64.astype(np.float32), nb.make_bodies(100)[0])
+
+
+def test_ic_known_values(nb):
+    # pinned so that a change of generator cannot go unnoticed (fixtures below depend on it)
+    p, v = nb.make_bodies(4096)
+    assert p[0].tolist() == pytest.approx([0.48312974, -0.68017924, -0.44279778, 1.0], abs=1e-8)
+    assert abs(float(p[:, :3].mean())) < 0.02 and abs(float(v[:, :3].mean())) < 0.02
+
+
+@pytest.mark.parametrize("n,P", [(10, 3), (1 << 20, 8), (4099, 7), (8, 8)])
+def test_slices_partition_the_bodies(nb, n, P):
+    S = nb.sharding
+    edges = [S.slice_first(q, n, P) for q in range(P + 1)]
+    assert edges[0] == 0 and edges[-1] == n
+    sizes = np.diff(edges)
+    assert sizes.min() >= n // P and sizes.max() <= n // P + 1
+    for sub in (1, 2, 5):
+        cover = []
+        for q in range(P):
+            for t in range(sub):
+                b, e = S.segment_bounds(q, t, n, P, sub)
+                assert edges[q] <= b <= e <= edges[q + 1]
+                cover.extend(range(b, e))
+        assert cover == list(range(n))
+
+
+def test_ring_schedule(nb):
+    S = nb.sharding
+    P = 5
+    have = {r: {r} for r in range(P)}
+    for s in range(1, P):
+        sends = {r: S.ring_schedule(r, P)[s - 1] for r in range(P)}
+        for r in range(P):
+            _, snd, rcv = sends[r]
+            assert snd in have[r]                       # a rank forwards only what it holds
+            assert sends[(r - 1) % P][1] == rcv         # what prev sends is what this rank receives
+        for r in range(P):
+            have[r].add(sends[r][2])
+    assert all(have[r] == set(range(P)) for r in range(P))
+
+
+def test_sharded_forces_any_arrival_order(nb, oracle):
+    """Partials combined in ascending source order do not depend on the order of arrival."""
+    pos, _ = nb.make_bodies(600, seed=3)
+    fn = lambda rows, src: oracle.forces_f32(rows, src)
+    for P, sub in ((3, 2), (4, 1)):
+        for r in range(P):
+            a = nb.sharding.sharded_forces(r, P, pos, sub, fn)
+            b = nb.sharding.sharded_forces(r, P, pos, sub, fn, arrival=list(range(P)))
+            c = nb.sharding.sharded_forces(r, P, pos, sub, fn, arrival=list(reversed(range(P))))
+            assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_mailbox_images(nb):
+    pos, _ = nb.make_bodies(77)
+    ram = nb.mailbox.encode_request(pos)
+    assert ram.shape == (78, 4) and ram.dtype == np.uint32
+    assert ram[0, 0] == 1 and ram[0, 1] == 77 and ram[0, 2] == 0 and ram[0, 3] == 0
+    assert np.array_equal(ram[1:].view(np.float32), pos)
+    with pytest.raises(ValueError):
+        nb.mailbox.encode_request(np.zeros((40000, 4), np.float32))   # NUM_PTS is 15 bits, S/top_level.vhd:45
