@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1 << 20, help="bodies (default: the metric's N = 1,048,576)")
     ap.add_argument("--fp64", action="store_true")
-    ap.add_argument("--variant", choices=["auto", "smem", "lds", "readlane"], default="auto")
+    ap.add_argument("--variant", choices=["auto", "smem", "lds", "readlane", "isa"], default="auto")
+    ap.add_argument("--isa-phase", type=int, default=-1)
     ap.add_argument("--iblock", type=int, default=0)
     ap.add_argument("--jsub", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
@@ -114,7 +115,9 @@ def main():
     n = args.n
     eng = D.make_engine(n, fp64=args.fp64, tile=args.tile)
     eng.set_option(nb.OPT_VARIANT, {"auto": nb.VARIANT_AUTO, "smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS,
-                                    "readlane": nb.VARIANT_READLANE}[args.variant])
+                                    "readlane": nb.VARIANT_READLANE, "isa": nb.VARIANT_ISA}[args.variant])
+    if args.isa_phase >= 0:
+        eng.set_option(nb.OPT_ISA_PHASE, args.isa_phase)
     eng.set_option(nb.OPT_IBLOCK, args.iblock)
     eng.set_option(nb.OPT_JSUB, args.jsub)
     eng.set_option(nb.OPT_COMM, nb.COMM_ALLGATHER if args.comm == "allgather" else nb.COMM_RING)

@@ -55,12 +55,16 @@ enum {
   NBODY_OPT_SUM_ORDER = 6, /* NBODY_SUM_* */
   NBODY_OPT_TIMING = 7,    /* 1: HIP events around every force kernel (nbody_kernel_time) */
   NBODY_OPT_COMM = 8,      /* NBODY_COMM_* (multi-GPU) */
-  NBODY_OPT_OVERLAP = 9    /* multi-GPU: 1 = start on the rank's own slice while the others travel (default), 0 = gather first */
+  NBODY_OPT_OVERLAP = 9,   /* multi-GPU: 1 = start on the rank's own slice while the others travel (default), 0 = gather first */
+  NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
+  NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: 4-byte phase (0/1) at which the loop's 64-bit encodings start (placement tuning) */
 };
 enum { NBODY_VARIANT_AUTO = 0,
        NBODY_VARIANT_SMEM = 1,     /* wave-uniform scalar loads (s_load_dwordx16) into SGPRs: no LDS, no VALU cost */
        NBODY_VARIANT_LDS = 2,      /* `tile` bodies staged in LDS per workgroup, broadcast ds_read_b128 */
-       NBODY_VARIANT_READLANE = 3  /* 64-body wave tile in VGPRs, v_readlane broadcast ("__shfl") */ };
+       NBODY_VARIANT_READLANE = 3, /* 64-body wave tile in VGPRs, v_readlane broadcast ("__shfl") */
+       NBODY_VARIANT_ISA = 4       /* SMEM delivery with the inner loop hand-scheduled in gfx950 ISA (uniform 64-bit encodings,
+                                      parity-safe registers); one body per lane, NBODY_ARITH_FMA3 only */ };
 enum { NBODY_ARITH_FMA3 = 0,       /* d2 = fma(dx,dx,fma(dy,dy,fma(dz,dz,eps))): 11 VALU + v_rsq_f32 per pair.  THE TIMED MODE */
        NBODY_ARITH_REFERENCE = 1,  /* d2 = (dx*dx+dy*dy)+fma(dz,dz,eps): the RTL's rounding points, S/dxy.vhd:113-122, S/dzsoft.vhd:201-202, S/dxyz_soft.vhd:149-150 */
        NBODY_ARITH_STRICT = 2,     /* FMA3 with 1/sqrt rounded once from an fp64 evaluation instead of v_rsq_f32 (1 ulp):

@@ -23,14 +23,15 @@
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 enum Test { T_FMA = 0, T_PKFMA, T_RSQ, T_MIX11_1, T_FMA_SGPR, T_READLANE, T_PKMUL, T_PKADD,
-            T_MIX_PK, T_SUB_SGPR, T_MIX22_2, T_RCP, T_SQRT, T_FMA_F64, T_RSQ_F64, T_MUL_F64, T_NTESTS };
+            T_MIX_PK, T_SUB_SGPR, T_MIX22_2, T_RCP, T_SQRT, T_FMA_F64, T_RSQ_F64, T_MUL_F64, T_BANK_SAME3, T_BANK_DIFF3, T_BANK_SAME2, T_FMAC_SAME, T_FMAC_DIFF, T_DEP_CHAIN, T_NTESTS };
 static const char* kNames[T_NTESTS] = {
   "v_fma_f32", "v_pk_fma_f32", "v_rsq_f32", "mix 11 fma + 1 rsq", "v_fma_f32 (sgpr src)",
   "v_readlane_b32", "v_pk_mul_f32", "v_pk_add_f32", "mix 11 pk_fma + 2 rsq (2 pairs)",
   "v_sub_f32 (sgpr src)", "mix 22 fma + 2 rsq (interleaved)", "v_rcp_f32", "v_sqrt_f32",
-  "v_fma_f64", "v_rsq_f64", "v_mul_f64" };
+  "v_fma_f64", "v_rsq_f64", "v_mul_f64", "v_fma_f32 3 srcs same VGPR bank", "v_fma_f32 3 srcs different banks",
+  "v_fma_f32 2 of 3 srcs same bank", "v_fmac_f32 (vop2) srcs same bank", "v_fmac_f32 (vop2) srcs diff banks", "pair chain (12 dependent ops, 1 chain)" };
 // instructions per BODY for cycle accounting
-static const int kInstr[T_NTESTS] = { 64, 64, 64, 48, 64, 64, 64, 64, 52, 64, 96, 64, 64, 64, 64, 64 };
+static const int kInstr[T_NTESTS] = { 64, 64, 64, 48, 64, 64, 64, 64, 52, 64, 96, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48 };
 
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -116,6 +117,38 @@ __global__ void __launch_bounds__(256) ubench(float* out, unsigned long long* cy
 #define X(k) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d##k) : "v"(db));
       R8(X) R8(X) R8(X) R8(X) R8(X) R8(X) R8(X) R8(X)
 #undef X
+    } else if constexpr (TEST == T_BANK_SAME3) {
+      // all three sources (and the destination) in VGPR bank 0 (register number mod 4)
+#define B8 "v_fma_f32 v32, v36, v40, v32\n v_fma_f32 v44, v36, v40, v44\n v_fma_f32 v48, v36, v40, v48\n v_fma_f32 v52, v36, v40, v52\n" \
+           "v_fma_f32 v56, v36, v40, v56\n v_fma_f32 v60, v36, v40, v60\n v_fma_f32 v64, v36, v40, v64\n v_fma_f32 v68, v36, v40, v68\n"
+      asm volatile(B8 B8 B8 B8 B8 B8 B8 B8 ::: "v32", "v36", "v40", "v44", "v48", "v52", "v56", "v60", "v64", "v68");
+#undef B8
+    } else if constexpr (TEST == T_BANK_DIFF3) {
+#define B8 "v_fma_f32 v32, v37, v42, v32\n v_fma_f32 v44, v37, v42, v44\n v_fma_f32 v48, v37, v42, v48\n v_fma_f32 v52, v37, v42, v52\n" \
+           "v_fma_f32 v56, v37, v42, v56\n v_fma_f32 v60, v37, v42, v60\n v_fma_f32 v64, v37, v42, v64\n v_fma_f32 v68, v37, v42, v68\n"
+      asm volatile(B8 B8 B8 B8 B8 B8 B8 B8 ::: "v32", "v37", "v42", "v44", "v48", "v52", "v56", "v60", "v64", "v68");
+#undef B8
+    } else if constexpr (TEST == T_BANK_SAME2) {
+#define B8 "v_fma_f32 v32, v36, v41, v32\n v_fma_f32 v44, v36, v41, v44\n v_fma_f32 v48, v36, v41, v48\n v_fma_f32 v52, v36, v41, v52\n" \
+           "v_fma_f32 v56, v36, v41, v56\n v_fma_f32 v60, v36, v41, v60\n v_fma_f32 v64, v36, v41, v64\n v_fma_f32 v68, v36, v41, v68\n"
+      asm volatile(B8 B8 B8 B8 B8 B8 B8 B8 ::: "v32", "v36", "v41", "v44", "v48", "v52", "v56", "v60", "v64", "v68");
+#undef B8
+    } else if constexpr (TEST == T_FMAC_SAME) {
+#define B8 "v_fmac_f32 v32, v36, v40\n v_fmac_f32 v44, v36, v40\n v_fmac_f32 v48, v36, v40\n v_fmac_f32 v52, v36, v40\n" \
+           "v_fmac_f32 v56, v36, v40\n v_fmac_f32 v60, v36, v40\n v_fmac_f32 v64, v36, v40\n v_fmac_f32 v68, v36, v40\n"
+      asm volatile(B8 B8 B8 B8 B8 B8 B8 B8 ::: "v32", "v36", "v40", "v44", "v48", "v52", "v56", "v60", "v64", "v68");
+#undef B8
+    } else if constexpr (TEST == T_FMAC_DIFF) {
+#define B8 "v_fmac_f32 v32, v37, v42\n v_fmac_f32 v44, v37, v42\n v_fmac_f32 v48, v37, v42\n v_fmac_f32 v52, v37, v42\n" \
+           "v_fmac_f32 v56, v37, v42\n v_fmac_f32 v60, v37, v42\n v_fmac_f32 v64, v37, v42\n v_fmac_f32 v68, v37, v42\n"
+      asm volatile(B8 B8 B8 B8 B8 B8 B8 B8 ::: "v32", "v37", "v42", "v44", "v48", "v52", "v56", "v60", "v64", "v68");
+#undef B8
+    } else if constexpr (TEST == T_DEP_CHAIN) {
+      // one pair interaction as the real kernel issues it for ONE body per lane: a serial dependent chain
+#define P1 "v_sub_f32 v33, %0, v37\n v_sub_f32 v34, %0, v38\n v_sub_f32 v35, %0, v39\n v_fma_f32 v36, v35, v35, v41\n v_fmac_f32 v36, v34, v34\n v_fmac_f32 v36, v33, v33\n" \
+           "v_rsq_f32 v36, v36\n v_mul_f32 v42, v36, v36\n v_mul_f32 v36, v36, v42\n v_fmac_f32 v43, v33, v36\n v_fmac_f32 v44, v34, v36\n v_fmac_f32 v45, v35, v36\n"
+      asm volatile(P1 P1 P1 P1 :: "s"(s) : "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v42", "v43", "v44", "v45");
+#undef P1
     } else if constexpr (TEST == T_RSQ_F64) {
 #define X(k) asm volatile("v_rsq_f64 %0, %0" : "+v"(d##k));
       R8(X) R8(X) R8(X) R8(X) R8(X) R8(X) R8(X) R8(X)
@@ -186,12 +219,16 @@ int main(int argc, char** argv) {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   fprintf(f, "# device %s  CUs=%d  clockRate=%d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
   int ncu = p.multiProcessorCount, iters = 4000;
+  if (!getenv("NB_ONLY_NEW")) {
   run<T_FMA>(f, ncu, iters);      run<T_PKFMA>(f, ncu, iters);   run<T_PKMUL>(f, ncu, iters);
   run<T_PKADD>(f, ncu, iters);    run<T_RSQ>(f, ncu, iters);     run<T_RCP>(f, ncu, iters);
   run<T_SQRT>(f, ncu, iters);     run<T_MIX11_1>(f, ncu, iters); run<T_MIX22_2>(f, ncu, iters);
   run<T_MIX_PK>(f, ncu, iters);   run<T_FMA_SGPR>(f, ncu, iters); run<T_SUB_SGPR>(f, ncu, iters);
   run<T_READLANE>(f, ncu, iters); run<T_FMA_F64>(f, ncu, iters); run<T_MUL_F64>(f, ncu, iters);
   run<T_RSQ_F64>(f, ncu, iters);
+  }
+  run<T_BANK_SAME3>(f, ncu, iters); run<T_BANK_DIFF3>(f, ncu, iters); run<T_BANK_SAME2>(f, ncu, iters);
+  run<T_FMAC_SAME>(f, ncu, iters); run<T_FMAC_DIFF>(f, ncu, iters); run<T_DEP_CHAIN>(f, ncu, iters);
   if (f != stdout) fclose(f);
   return 0;
 }

@@ -98,7 +98,7 @@ struct Local {
 
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
-  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_RING, overlap = 1;
+  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_RING, overlap = 1, isa_phase = 0, waves_per_simd = 0;
 };
 
 struct Global {
@@ -121,29 +121,33 @@ inline char* word_ptr(void* base, size_t word) { return (char*)base + word * wor
 
 int blocks_for(int rows, int R) { return (rows + kBlock * R - 1) / (kBlock * R); }
 
-// Choose R (bodies per lane) and sub (pieces per source slice) so that one launch over ONE slice
-// already puts >= 4 waves on every SIMD (1024 workgroups of 4 waves on 256 CUs): the 11+1 issue
-// mix needs 3-4 waves per SIMD to reach 30 cycles per pair-wave (profiles/r01_microbench_valu_issue.txt).
+// Choose R (bodies per lane) and sub (pieces per source slice).  Measured at N = 1M on MI355X (profiles/r01_sweep.txt):
+// one body per lane (16 waves per SIMD worth of work, 8 resident) beats 2/4/8 bodies per lane — hipcc software-pipelines
+// the 8 sources of a scalar-load group across the single chain, and more resident waves hide the transcendental — and
+// cutting the sources into pieces so that a launch has >= 16k workgroups adds ~8 % (load balance across the 256 CUs).
 void resolve_config() {
   const int n_local = g.loc[0].n_local > 0 ? g.loc[0].n_local : 1;
   g.nslices = g.nranks > 1 ? g.nranks : (g.opt.jslices > 0 ? g.opt.jslices : 1);
   g.variant = g.opt.variant == NBODY_VARIANT_AUTO ? NBODY_VARIANT_SMEM : g.opt.variant;
   if (g.fp64) g.variant = NBODY_VARIANT_SMEM;
+  // the hand-scheduled loop exists for the timed arithmetic only; the study modes use the C++ kernels
+  if (g.variant == NBODY_VARIANT_ISA && (g.opt.arith != NBODY_ARITH_FMA3 || g.opt.sum_order != NBODY_SUM_SEQ)) g.variant = NBODY_VARIANT_SMEM;
   int R = g.opt.iblock;
-  const int target_blocks = 4 * (g.cu_count > 0 ? g.cu_count : 256);
-  if (R == 0) {
-    R = g.fp64 ? 2 : 4;
-    while (R > 1 && blocks_for(n_local, R) < target_blocks / 4) R >>= 1;
-  }
+  if (R == 0) R = (g.variant == NBODY_VARIANT_LDS || g.variant == NBODY_VARIANT_READLANE) ? 2 : 1;
+  if (g.variant == NBODY_VARIANT_ISA) R = 1;
   if (g.fp64 && R > 4) R = 4;
   if (g.opt.sum_order == NBODY_SUM_FPGA16 && !g.fp64) R = 1;
   g.R = R;
   int sub = g.opt.jsub;
   if (sub == 0) {
+    const int cus = g.cu_count > 0 ? g.cu_count : 256;
+    // one GPU: 64 workgroups per CU in the launch; several GPUs: the launch over the rank's OWN slice alone
+    // (which runs while the other slices travel) already has 16 per CU
+    const int target_blocks = (g.nslices > 1 ? 16 : 64) * cus;
     int b = blocks_for(n_local, R);
     sub = (target_blocks + b - 1) / b;
     int slice_len = g.n / g.nslices;
-    int max_sub = std::max(1, slice_len / 256);   // keep >= 256 sources per segment
+    int max_sub = std::max(1, slice_len / 2048);   // keep >= 2048 sources per segment
     sub = std::max(1, std::min(std::min(sub, 32), max_sub));
   }
   g.sub = sub;
@@ -210,7 +214,13 @@ int launch_timed(Local& L, K kernel, dim3 grid, const ForceArgs& a) {
     idx = L.t_head;
     HIPC(hipEventRecord(L.t0[idx], L.compute));
   }
-  hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, L.compute, a);
+  // optional occupancy cap: k workgroups (= k waves per SIMD) per CU by giving each 160 KiB / k of dynamic LDS
+  size_t dyn_lds = 0;
+  if (g.opt.waves_per_simd > 0 && g.opt.waves_per_simd < 8) {
+    dyn_lds = (size_t)(160 * 1024) / (size_t)g.opt.waves_per_simd - 512 - (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0);
+    if (dyn_lds > 64 * 1024) HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(kBlock), dyn_lds, L.compute, a);
   HIPC(hipGetLastError());
   if (idx >= 0) {
     HIPC(hipEventRecord(L.t1[idx], L.compute));
@@ -281,6 +291,14 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, bo
       case NBODY_ARITH_STRICT: return launch_timed(L, force_fpga16_f32<2>, grid, a);
       case NBODY_ARITH_REFERENCE_STRICT: return launch_timed(L, force_fpga16_f32<3>, grid, a);
       default: return launch_timed(L, force_fpga16_f32<0>, grid, a);
+    }
+  }
+  if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
+    switch (g.opt.isa_phase) {
+      case 1: return launch_timed(L, force_isa_f32<1>, grid, a);
+      case 2: return launch_timed(L, force_isa_f32<2>, grid, a);
+      case 3: return launch_timed(L, force_isa_f32<3>, grid, a);
+      default: return launch_timed(L, force_isa_f32<0>, grid, a);
     }
   }
   switch (R) {
@@ -728,7 +746,7 @@ void nbody_shutdown(void) {
 
 int nbody_set_option(int key, int value) {
   switch (key) {
-    case NBODY_OPT_VARIANT: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.variant = value; break;
+    case NBODY_OPT_VARIANT: if (value < 0 || value > 4) return NBODY_ERR_ARG; g.opt.variant = value; break;
     case NBODY_OPT_IBLOCK: if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NBODY_ERR_ARG; g.opt.iblock = value; break;
     case NBODY_OPT_JSUB: if (value < 0 || value > 256) return NBODY_ERR_ARG; g.opt.jsub = value; break;
     case NBODY_OPT_JSLICES: if (value < 0 || value > kMaxRanks) return NBODY_ERR_ARG; g.opt.jslices = value; break;
@@ -737,6 +755,8 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
     case NBODY_OPT_COMM: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: g.opt.overlap = value ? 1 : 0; break;
+    case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
+    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); return reconfigure(); }

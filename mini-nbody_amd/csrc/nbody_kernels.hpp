@@ -74,6 +74,12 @@ __device__ __host__ inline void segment_bounds(int q, int t, int n, int P, int s
   *jb = b; *je = e;
 }
 
+// v_readlane_b32: the value lane k holds, as a wave-uniform scalar.  Takes the float BY VALUE:
+// __builtin_bit_cast applied directly to an ext-vector element (v.y) reads element 0 with this compiler.
+__device__ __forceinline__ float lane_bcast(float v, int k) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+
 __device__ __forceinline__ float soft_f32() { return __builtin_bit_cast(float, kSoftBits); }
 
 // ---------------------------------------------------------------------------
@@ -233,6 +239,58 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// ISA variant: the SMEM kernel with its inner loop written instruction by instruction
+// (force_loop_gfx950.inc, generated by tools/gen_force_loop.py, which explains the three hardware
+// facts it is built on).  One body per lane; same arithmetic, same order, same bits as
+// force_smem_f32<1, 0>.  PHASE selects the 4-byte phase at which the loop's 64-bit encodings start.
+#include "force_loop_gfx950.inc"
+template <int PHASE>
+__global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
+  int seg, jb, je;
+  block_segment(a, &seg, &jb, &je);
+  const float eps = soft_f32();
+  const f4* rows = (const f4*)a.rows;
+  const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
+  const int row_end = a.row0 + a.row_count;
+  const f4 me = rows[i < row_end ? i : row_end - 1];
+  const float xi = me.x, yi = me.y, zi = me.z;
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  int j = jb;
+  const int groups = (je - jb) / NB_FORCE_LOOP_GROUP;
+  if (groups > 0) {
+    const uint64_t p = (uint64_t)(uintptr_t)a.src + (uint64_t)jb * sizeof(f4);
+    if constexpr (PHASE == 0) {
+      asm volatile(NB_FORCE_LOOP_PHASE0
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PHASE == 1) {
+      asm volatile(NB_FORCE_LOOP_PHASE1
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PHASE == 2) {   // bring-up: timing only, wrong results
+      asm volatile(NB_FORCE_LOOP_DBG_NORELOAD
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_CLOBBERS);
+    } else {
+      asm volatile(NB_FORCE_LOOP_DBG_SERIAL
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_CLOBBERS);
+    }
+    j += groups * NB_FORCE_LOOP_GROUP;
+  }
+  const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
+  for (; j < je; ++j) {
+    f4 q = src[j];
+    pair_f32<0>(q.x, q.y, q.z, xi, yi, zi, eps, ax, ay, az);
+  }
+  if (i < row_end) epilogue_f32(a, seg, i, xi, yi, zi, me.w, ax, ay, az);
+}
+
+// ---------------------------------------------------------------------------
 // LDS variant (the north_star's "source bodies tiled into LDS", tile = 256 by
 // default).  Double-buffered: the global loads of tile t+1 are issued before
 // the compute on tile t and written to the other buffer after it, one barrier
@@ -332,17 +390,17 @@ __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
     if (cnt == 64) {
 #pragma unroll
       for (int k = 0; k < 64; ++k) {
-        float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.x), k));
-        float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.y), k));
-        float zj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.z), k));
+        float xj = lane_bcast(cur.x, k);
+        float yj = lane_bcast(cur.y, k);
+        float zj = lane_bcast(cur.z, k);
 #pragma unroll
         for (int r = 0; r < R; ++r) pair_f32<ARITH>(xj, yj, zj, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
       }
     } else {
       for (int k = 0; k < cnt; ++k) {
-        float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.x), k));
-        float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.y), k));
-        float zj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.z), k));
+        float xj = lane_bcast(cur.x, k);
+        float yj = lane_bcast(cur.y, k);
+        float zj = lane_bcast(cur.z, k);
 #pragma unroll
         for (int r = 0; r < R; ++r) pair_f32<ARITH>(xj, yj, zj, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
       }

@@ -42,7 +42,7 @@ class NBody:
 
     @property
     def config(self):
-        names = {L.VARIANT_SMEM: "smem", L.VARIANT_LDS: "lds", L.VARIANT_READLANE: "readlane"}
+        names = {L.VARIANT_SMEM: "smem", L.VARIANT_LDS: "lds", L.VARIANT_READLANE: "readlane", L.VARIANT_ISA: "isa"}
         return dict(variant=names.get(self.info(L.INFO_VARIANT), "?"), iblock=self.info(L.INFO_IBLOCK),
                     jsub=self.info(L.INFO_JSUB), nseg=self.info(L.INFO_NSEG), tile=self.info(L.INFO_TILE),
                     n_local=self.info(L.INFO_N_LOCAL), first_body=self.info(L.INFO_FIRST_BODY),

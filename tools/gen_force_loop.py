@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Generate mini-nbody_amd/csrc/force_loop_gfx950.inc — the hand-scheduled inner loop of the fp32 force kernel.
+
+Why hand-written ISA (measurements: profiles/r01_microbench_streams.txt, tools/gen_streams.py):
+  * every instruction of the pair interaction issues at 2 cycles per wave64 EXCEPT that the cost of the
+    quarter-rate v_rsq_f32 depends on code placement: with uniform 64-bit encodings the stream costs 2.6
+    cycles/instruction (31.5 per pair) when instructions start at one 4-byte phase of an 8-byte window and 3.9
+    (47 per pair) at the other; hipcc's mix of 32- and 64-bit encodings drifts between the two (34-36 per pair);
+  * a VOP3 instruction whose three VGPR sources have the same parity (register number mod 2) costs 4 cycles instead
+    of 2: temporaries are pinned to physical registers, t/u even, dx/dy/dz odd, so no instruction does that;
+  * gfx940+ needs one wait state between a transcendental and a VALU instruction that reads its result
+    (hipcc does not pad inline asm): the loop is software-pipelined by one stage so that three independent
+    subtractions (or two scalar instructions) sit between every v_rsq_f32 and its first consumer.
+
+Loop shape (one wave, one body i per lane, sources delivered as wave-uniform scalar loads):
+    A = s[36:51], B = s[52:67]: two buffers of 4 bodies {x,y,z,w}; pointer s[68:69], group counter s70, stride s71
+    prologue: load A
+    loop:  wait A | load B | 4 bodies from A (48 VALU) | advance pointer | wait B | load A (next group) | 4 bodies from B
+The arithmetic and its order per body are exactly pair_f32<0> of nbody_kernels.hpp (sources ascending), so the
+result is bit-identical to the C++ kernels.
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "mini-nbody_amd", "csrc", "force_loop_gfx950.inc")
+
+T, U = 20, 22                      # even
+DSETS = [(21, 23, 25), (27, 29, 31)]   # odd
+A_BASE, B_BASE = 36, 52
+PTR, CNT, STRIDE = 68, 70, 71
+
+
+def S(b, sbase, dset):
+    dx, dy, dz = DSETS[dset]
+    s = sbase + 4 * b
+    return ["v_sub_f32_e64 v%d, s%d, %%[xi]" % (dx, s), "v_sub_f32_e64 v%d, s%d, %%[yi]" % (dy, s + 1),
+            "v_sub_f32_e64 v%d, s%d, %%[zi]" % (dz, s + 2)]
+
+
+def F(dset):
+    dx, dy, dz = DSETS[dset]
+    return ["v_fma_f32 v%d, v%d, v%d, %%[eps]" % (T, dz, dz), "v_fma_f32 v%d, v%d, v%d, v%d" % (T, dy, dy, T),
+            "v_fma_f32 v%d, v%d, v%d, v%d" % (T, dx, dx, T)]
+
+
+def R():
+    return ["v_rsq_f32_e64 v%d, v%d" % (T, T)]
+
+
+def M(dset):
+    dx, dy, dz = DSETS[dset]
+    return ["v_mul_f32_e64 v%d, v%d, v%d" % (U, T, T), "v_mul_f32_e64 v%d, v%d, v%d" % (T, T, U),
+            "v_fma_f32 %%[ax], v%d, v%d, %%[ax]" % (dx, T), "v_fma_f32 %%[ay], v%d, v%d, %%[ay]" % (dy, T),
+            "v_fma_f32 %%[az], v%d, v%d, %%[az]" % (dz, T)]
+
+
+def half(sbase, filler):
+    """4 bodies from one SGPR buffer; `filler` = the two 4-byte scalar instructions that separate the last
+    v_rsq_f32 from its consumer (wait state) and keep the 8-byte phase."""
+    out = []
+    out += S(0, sbase, 0) + F(0) + R()
+    for b in (1, 2, 3):
+        d, pd = b & 1, (b - 1) & 1
+        out += S(b, sbase, d) + M(pd) + F(d) + R()
+    out += filler + M(1)
+    return out
+
+
+def half_serial(sbase):
+    """no software pipelining: S F R nop nop M per body (the two s_nop are the trans->VALU wait state, 8 bytes)"""
+    out = []
+    for b in range(4):
+        out += S(b, sbase, 0) + F(0) + R() + ["s_nop 0", "s_nop 0"] + M(0)
+    return out
+
+
+def build_debug(kind):
+    """timing-only / alternative loops selected by NBODY_OPT_ISA_PHASE >= 2 (bring-up, not used by default)"""
+    ins = []
+    ins.append("s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1))
+    ins.append("s_mov_b32 s%d, %%[groups]" % CNT)
+    ins.append("s_movk_i32 s%d, 0x80" % STRIDE)
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    if kind == "noreload":
+        ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+        ins.append("s_waitcnt lgkmcnt(0)")
+    ins += [".p2align 3", "s_nop 0", "1:"]
+    if kind == "noreload":       # WRONG RESULTS (same 8 sources every time): prices the scalar loads
+        ins += ["s_nop 0", "s_nop 0"]
+        ins += half(A_BASE, ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)])
+        ins += ["s_nop 0", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+        ins += half(B_BASE, ["s_nop 0", "s_nop 0"])
+    elif kind == "serial":
+        ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+        ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+        ins += half_serial(A_BASE)
+        ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+        ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+        ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+        ins += half_serial(B_BASE)
+    ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b", "s_waitcnt lgkmcnt(0)"]
+    return ins
+
+
+T2 = [20, 24]                       # two d2/inv/inv3 registers (even), alternating with the body index
+
+
+def body_defA(k, sbase, b):
+    """ord_defA of tools/gen_streams.py (2.63 cycles/instruction in the stream microbenchmark):
+         S S S F F F R | A A A of the previous body | M M
+    The previous body's three accumulating fmas are the wait state between v_rsq_f32 and its consumer."""
+    t, tp = T2[k & 1], T2[(k - 1) & 1]
+    dx, dy, dz = DSETS[k & 1]
+    px, py, pz = DSETS[(k - 1) & 1]
+    s0 = sbase + 4 * b
+    return [
+        "v_sub_f32_e64 v%d, s%d, %%[xi]" % (dx, s0), "v_sub_f32_e64 v%d, s%d, %%[yi]" % (dy, s0 + 1), "v_sub_f32_e64 v%d, s%d, %%[zi]" % (dz, s0 + 2),
+        "v_fma_f32 v%d, v%d, v%d, %%[eps]" % (t, dz, dz), "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dy, dy, t), "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dx, dx, t),
+        "v_rsq_f32_e64 v%d, v%d" % (t, t),
+        "v_fma_f32 %%[ax], v%d, v%d, %%[ax]" % (px, tp), "v_fma_f32 %%[ay], v%d, v%d, %%[ay]" % (py, tp), "v_fma_f32 %%[az], v%d, v%d, %%[az]" % (pz, tp),
+        "v_mul_f32_e64 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e64 v%d, v%d, v%d" % (t, t, U)]
+
+
+def build_defA(phase_nop):
+    ins = []
+    ins.append("s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1))
+    ins.append("s_mov_b32 s%d, %%[groups]" % CNT)
+    ins.append("s_movk_i32 s%d, 0x80" % STRIDE)
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    # "previous body" of the very first body: d = 0, inv3 = 0 -> fma(0, 0, acc) leaves acc as it is
+    px, py, pz = DSETS[1]
+    ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
+    ins.append(".p2align 3")
+    if phase_nop:
+        ins.append("s_nop 0")
+    ins.append("1:")
+    ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+    for b in range(4):
+        ins += body_defA(b, A_BASE, b)
+    ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+    ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    for b in range(4):
+        ins += body_defA(4 + b, B_BASE, b)
+    ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b"]
+    # drain: the accumulate of the last body (body 7 -> d set 1, t register 1), then retire the unused prefetch
+    ins += ["v_fma_f32 %%[ax], v%d, v%d, %%[ax]" % (px, T2[1]), "v_fma_f32 %%[ay], v%d, v%d, %%[ay]" % (py, T2[1]),
+            "v_fma_f32 %%[az], v%d, v%d, %%[az]" % (pz, T2[1])]
+    ins += ["s_waitcnt lgkmcnt(0)"]
+    return ins
+
+
+def build(phase_nop):
+    ins = []
+    ins.append("s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1))
+    ins.append("s_mov_b32 s%d, %%[groups]" % CNT)
+    ins.append("s_movk_i32 s%d, 0x80" % STRIDE)
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    ins.append(".p2align 3")
+    if phase_nop:
+        ins.append("s_nop 0")
+    ins.append("1:")
+    ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+    ins += half(A_BASE, ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)])
+    ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    ins += half(B_BASE, ["s_nop 0", "s_nop 0"])
+    ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b"]
+    ins += ["s_waitcnt lgkmcnt(0)"]      # the prefetched (unused) A of the group after the last
+    return ins
+
+
+def clobbers():
+    regs = ["v%d" % r for r in [T, U] + T2 + [x for d in DSETS for x in d]]
+    regs = sorted(set(regs), key=lambda r: int(r[1:]))
+    regs += ["s%d" % r for r in range(A_BASE, STRIDE + 1)]
+    return regs + ["scc", "memory"]
+
+
+def main():
+    with open(OUT, "w") as f:
+        f.write("// GENERATED by tools/gen_force_loop.py — do not edit.  See that file for the why.\n")
+        for name, nop in (("NB_FORCE_LOOP_PHASE0", False), ("NB_FORCE_LOOP_PHASE1", True)):
+            text = "\\n\\t".join(build_defA(nop))
+            f.write("#define %s \"%s\"\n" % (name, text))
+        for name, kind in (("NB_FORCE_LOOP_DBG_NORELOAD", "noreload"), ("NB_FORCE_LOOP_DBG_SERIAL", "serial")):
+            f.write("#define %s \"%s\"\n" % (name, "\\n\\t".join(build_debug(kind))))
+        f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clobbers()))
+        f.write("#define NB_FORCE_LOOP_GROUP 8\n")
+    n_valu = len([i for i in build_defA(False) if i.startswith("v_")])
+    print("wrote %s (%d VALU instructions per group of 8 bodies)" % (OUT, n_valu))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Kernel configuration sweep on one GPU: (variant, bodies per lane, source sub-segments) -> G pairs/s from the
+HIP-event time of the force kernels.  One process, interleaved rounds (cdna guide §5.4 rule 24).
+usage: python tools/sweep.py [--n N] [--steps K] [--rounds M] [--configs "smem:4:1,lds:2:4,..."]"""
+import argparse
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--configs", default="")
+    args = ap.parse_args()
+    nb = importlib.import_module("mini-nbody_amd")
+    import numpy as np
+    n = args.n
+    if args.configs:
+        cfgs = [tuple(c.split(":")) for c in args.configs.split(",")]
+        cfgs = [(c[0], int(c[1]), int(c[2]), int(c[3]) if len(c) > 3 else 0) for c in cfgs]
+    else:
+        cfgs = [(v, r, s, 0) for v in ("smem", "lds") for r in (1, 2, 4) for s in (1, 2, 4, 8)]
+    pos, vel = nb.make_bodies(n, dtype=np.float64 if args.fp64 else np.float32)
+    eng = nb.NBody(n, fp64=args.fp64, tile=args.tile)
+    eng.set_option(nb.OPT_TIMING, 1)
+    vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, "isa0": nb.VARIANT_ISA, "isa1": nb.VARIANT_ISA, "isa2": nb.VARIANT_ISA, "isa3": nb.VARIANT_ISA}
+    res = {c: [] for c in cfgs}
+    for rnd in range(args.rounds):
+        for c in cfgs:
+            v, r, s, w = c
+            eng.set_option(nb.OPT_WAVES_PER_SIMD, w)
+            eng.set_option(nb.OPT_VARIANT, vmap[v])
+            eng.set_option(nb.OPT_ISA_PHASE, int(v[3]) if v.startswith("isa") else 0)
+            eng.set_option(nb.OPT_IBLOCK, r)
+            eng.set_option(nb.OPT_JSUB, s)
+            eng.upload(pos, vel)
+            eng.step(0.01, 1)
+            eng.sync()
+            eng.kernel_time(reset=True)
+            eng.step(0.01, args.steps)
+            eng.sync()
+            ms, cnt = eng.kernel_time(reset=True)
+            res[c].append(float(n) * n * args.steps / (ms * 1e-3) / 1e9)
+    bound = 256 * 4 * 64 / 30 * 2.4
+    print("# n=%d steps=%d rounds=%d; issue bound %.0f G/s at 2.4 GHz" % (n, args.steps, args.rounds, bound))
+    for c in sorted(cfgs, key=lambda c: -max(res[c])):
+        print("%-9s R=%d jsub=%-3d waves/SIMD<=%d  best %7.1f  median %7.1f G pairs/s  (%.1f %% of issue bound)"
+              % (c[0], c[1], c[2], c[3] or 8, max(res[c]), sorted(res[c])[len(res[c]) // 2], 100 * max(res[c]) / bound), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
