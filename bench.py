@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="bodies (default: the metric's N = 1,048,576)")
+    ap.add_argument("--bodies", dest="n", type=int, default=1 << 20, help="bodies (default: the metric N = 1,048,576)")
     ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--variant", choices=["auto", "smem", "lds", "readlane", "isa"], default="auto")
     ap.add_argument("--isa-phase", type=int, default=-1)
