@@ -98,7 +98,7 @@ struct Local {
 
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
-  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_RING, overlap = 1, isa_phase = 0, waves_per_simd = 0;
+  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_RING, overlap = 1, isa_phase = 1, waves_per_simd = 0;
 };
 
 struct Global {
@@ -128,7 +128,8 @@ int blocks_for(int rows, int R) { return (rows + kBlock * R - 1) / (kBlock * R);
 void resolve_config() {
   const int n_local = g.loc[0].n_local > 0 ? g.loc[0].n_local : 1;
   g.nslices = g.nranks > 1 ? g.nranks : (g.opt.jslices > 0 ? g.opt.jslices : 1);
-  g.variant = g.opt.variant == NBODY_VARIANT_AUTO ? NBODY_VARIANT_SMEM : g.opt.variant;
+  // AUTO: the hand-scheduled ISA loop (+6 % over hipcc's schedule of the same operations, profiles/r01_sweep_isa.txt)
+  g.variant = g.opt.variant == NBODY_VARIANT_AUTO ? NBODY_VARIANT_ISA : g.opt.variant;
   if (g.fp64) g.variant = NBODY_VARIANT_SMEM;
   // the hand-scheduled loop exists for the timed arithmetic only; the study modes use the C++ kernels
   if (g.variant == NBODY_VARIANT_ISA && (g.opt.arith != NBODY_ARITH_FMA3 || g.opt.sum_order != NBODY_SUM_SEQ)) g.variant = NBODY_VARIANT_SMEM;
@@ -298,6 +299,20 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, bo
       case 1: return launch_timed(L, force_isa_f32<1>, grid, a);
       case 2: return launch_timed(L, force_isa_f32<2>, grid, a);
       case 3: return launch_timed(L, force_isa_f32<3>, grid, a);
+      case 4: return launch_timed(L, force_isa_f32<4>, grid, a);
+      case 5: return launch_timed(L, force_isa_f32<5>, grid, a);
+      case 6: return launch_timed(L, force_isa_f32<6>, grid, a);
+      case 7: return launch_timed(L, force_isa_f32<7>, grid, a);
+      case 8: return launch_timed(L, force_isa_f32<8>, grid, a);
+      case 9: return launch_timed(L, force_isa_f32<9>, grid, a);
+      case 10: return launch_timed(L, force_isa_f32<10>, grid, a);
+      case 11: return launch_timed(L, force_isa_f32<11>, grid, a);
+      case 12: return launch_timed(L, force_isa_f32<12>, grid, a);
+      case 13: return launch_timed(L, force_isa_f32<13>, grid, a);
+      case 20: return launch_timed(L, force_isa_f32<20>, grid, a);
+      case 21: return launch_timed(L, force_isa_f32<21>, grid, a);
+      case 22: return launch_timed(L, force_isa_f32<22>, grid, a);
+      case 23: return launch_timed(L, force_isa_f32<23>, grid, a);
       default: return launch_timed(L, force_isa_f32<0>, grid, a);
     }
   }
@@ -756,7 +771,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_COMM: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: g.opt.overlap = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
-    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
+    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 23) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); return reconfigure(); }

@@ -121,6 +121,26 @@ def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engin
     assert np.all(ref[:, 3] == 0)   # S/compute_store.vhd:242: the 4th word is 0
 
 
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 100, 1031])
+def test_isa_loop_equals_compiled_kernel_ragged(nb, engine_factory, n):
+    """Default (hand-scheduled ISA loop, groups of 8 sources + scalar tail) vs the hipcc-scheduled kernel: same bits."""
+    pos, vel = nb.make_bodies(n, seed=100 + n)
+    eng = engine_factory(n)
+    eng.set_option(nb.OPT_JSUB, 1)
+    assert eng.config["variant"] == "isa"
+    a = eng.forces(pos)
+    eng.upload(pos, vel)
+    eng.step(0.01, 3)
+    pa, va = eng.download()
+    eng.set_option(nb.OPT_VARIANT, nb.VARIANT_SMEM)
+    assert eng.config["variant"] == "smem"
+    assert np.array_equal(bits(a), bits(eng.forces(pos)))
+    eng.upload(pos, vel)
+    eng.step(0.01, 3)
+    pb, vb = eng.download()
+    assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(va), bits(vb))
+
+
 def test_segmentation_matches_host_mirror_bitwise(nb, oracle_fast, engine_factory):
     """jslices x jsub segments combined in ascending order == the Python mirror of the decomposition
     (mini-nbody_amd/sharding.py) driven by the oracle, bit for bit in strict mode."""

@@ -130,9 +130,13 @@ def build_defA(phase_nop):
     # "previous body" of the very first body: d = 0, inv3 = 0 -> fma(0, 0, acc) leaves acc as it is
     px, py, pz = DSETS[1]
     ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
-    ins.append(".p2align 3")
-    if phase_nop:
-        ins.append("s_nop 0")
+    if isinstance(phase_nop, bool):
+        ins.append(".p2align 3")
+        if phase_nop:
+            ins.append("s_nop 0")
+    else:                       # deterministic placement: loop head = 4 * phase_nop bytes past a 64-byte line
+        ins.append(".p2align 6")
+        ins += ["s_nop 0"] * int(phase_nop)
     ins.append("1:")
     ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
     ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
@@ -172,21 +176,134 @@ def build(phase_nop):
     return ins
 
 
+def build_variant(v):
+    """Numbered loops for NBODY_OPT_ISA_PHASE (0/1 are the product phases; >= 2 are bring-up experiments).
+    All use the deferred-accumulate order; what differs is how the scalar loads are handled."""
+    if v == 0:
+        return build_defA(False)
+    if v == 1:
+        return build_defA(True)
+    if 6 <= v < 14:             # placement sweep: loop head at 64-byte line + 4 * (2m + 1) bytes, m = v - 6
+        return build_defA(2 * (v - 6) + 1)
+    ins = []
+    ins.append("s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1))
+    ins.append("s_mov_b32 s%d, %%[groups]" % CNT)
+    ins.append("s_movk_i32 s%d, 0x80" % STRIDE)
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    px, py, pz = DSETS[1]
+    ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
+    if v in (2, 3):
+        ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+        ins.append("s_waitcnt lgkmcnt(0)")
+    ins += [".p2align 3", "s_nop 0", "1:"]
+    if v == 2:      # TIMING ONLY: no loads, no waits in the loop
+        ins += ["s_nop 0", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+        for b in range(4):
+            ins += body_defA(b, A_BASE, b)
+        ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+        for b in range(4):
+            ins += body_defA(4 + b, B_BASE, b)
+    elif v == 3:    # TIMING ONLY: loads into SCRATCH SGPRs (s72..s87) that nothing reads, with the waits
+        ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+        ins.append("s_load_dwordx16 s[72:87], s[%d:%d], 0x40" % (PTR, PTR + 1))
+        for b in range(4):
+            ins += body_defA(b, A_BASE, b)
+        ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+        ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+        ins.append("s_load_dwordx16 s[72:87], s[%d:%d], 0x0" % (PTR, PTR + 1))
+        for b in range(4):
+            ins += body_defA(4 + b, B_BASE, b)
+    elif v == 4:    # loads issued in the MIDDLE of the other half (two bodies in), waits at the half boundaries
+        ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+        for b in range(4):
+            if b == 2:
+                ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+            ins += body_defA(b, A_BASE, b)
+        ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+        ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+        for b in range(4):
+            if b == 2:
+                ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+            ins += body_defA(4 + b, B_BASE, b)
+    elif v == 5:    # eight s_load_dwordx4 (one body each) instead of two x16, issued one body ahead of use
+        # buffers: body b of the group lives in s[36+4b : 39+4b]; body b+8's load is issued right after body b's subs
+        ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+        ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+        for b in range(4):
+            ins += body_defA(b, A_BASE, b)
+        ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+        ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+        for q in range(4):
+            ins.append("s_load_dwordx4 s[%d:%d], s[%d:%d], 0x%x" % (A_BASE + 4 * q, A_BASE + 4 * q + 3, PTR, PTR + 1, 16 * q))
+        for b in range(4):
+            ins += body_defA(4 + b, B_BASE, b)
+    ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b"]
+    ins += ["v_fma_f32 %%[ax], v%d, v%d, %%[ax]" % (px, T2[1]), "v_fma_f32 %%[ay], v%d, v%d, %%[ay]" % (py, T2[1]),
+            "v_fma_f32 %%[az], v%d, v%d, %%[az]" % (pz, T2[1])]
+    ins += ["s_waitcnt lgkmcnt(0)"]
+    return ins
+
+
+def build_g16(pad, group=16):
+    """16 (or 8) bodies per iteration, sources addressed as base s[68:69] + byte offset s70 (+ immediate), one 32-bit
+    add per iteration, count-down fused with the branch (s_add_u32 cnt, cnt, -1 sets SCC while cnt was >= 1).
+    Buffers: A = s[36:67] (8 bodies, two x16 loads), B = s[72:103]?  SGPRs end at s101, so B = s[72:99] + ... does not
+    fit: use A = s[36:67], B = s[4..]?  -> keep to what fits: group 16 = buffers of 8 bodies at s[36:67] and s[68:99],
+    pointer s[100:101], offset and counter in the two operands the compiler supplies (%[off], %[cnt])."""
+    a_base, b_base = 36, 68
+    half_bodies = group // 2
+    ins = []
+    for q in range(half_bodies // 4):
+        ins.append("s_load_dwordx16 s[%d:%d], %%[p], %%[off] offset:0x%x" % (a_base + 16 * q, a_base + 16 * q + 15, 64 * q))
+    px, py, pz = DSETS[1]
+    ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
+    ins.append(".p2align 6")
+    ins += ["s_nop 0"] * pad
+    ins.append("1:")
+    stride = 16 * group
+    # half 1: wait for A, fetch B, compute A
+    ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+    for q in range(half_bodies // 4):
+        ins.append("s_load_dwordx16 s[%d:%d], %%[p], %%[off] offset:0x%x" % (b_base + 16 * q, b_base + 16 * q + 15, 16 * half_bodies + 64 * q))
+    for b in range(half_bodies):
+        ins += body_defA(b, a_base, b)
+    # half 2: advance, wait for B, fetch next A, compute B
+    ins += ["s_add_u32 %%[off], %%[off], 0x%x" % stride]          # 8 bytes (32-bit literal)
+    ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+    for q in range(half_bodies // 4):
+        ins.append("s_load_dwordx16 s[%d:%d], %%[p], %%[off] offset:0x%x" % (a_base + 16 * q, a_base + 16 * q + 15, 64 * q))
+    for b in range(half_bodies):
+        ins += body_defA(half_bodies + b, b_base, b)
+    ins += ["s_add_u32 %[cnt], %[cnt], -1", "s_cbranch_scc1 1b"]
+    last = (group - 1) & 1
+    lx, ly, lz = DSETS[last]
+    ins += ["v_fma_f32 %%[ax], v%d, v%d, %%[ax]" % (lx, T2[last]), "v_fma_f32 %%[ay], v%d, v%d, %%[ay]" % (ly, T2[last]),
+            "v_fma_f32 %%[az], v%d, v%d, %%[az]" % (lz, T2[last])]
+    ins += ["s_waitcnt lgkmcnt(0)"]
+    return ins
+
+
+N_VARIANTS = 14
+
+
 def clobbers():
     regs = ["v%d" % r for r in [T, U] + T2 + [x for d in DSETS for x in d]]
     regs = sorted(set(regs), key=lambda r: int(r[1:]))
-    regs += ["s%d" % r for r in range(A_BASE, STRIDE + 1)]
+    regs += ["s%d" % r for r in range(A_BASE, 88)]
     return regs + ["scc", "memory"]
 
 
 def main():
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_force_loop.py — do not edit.  See that file for the why.\n")
-        for name, nop in (("NB_FORCE_LOOP_PHASE0", False), ("NB_FORCE_LOOP_PHASE1", True)):
-            text = "\\n\\t".join(build_defA(nop))
-            f.write("#define %s \"%s\"\n" % (name, text))
-        for name, kind in (("NB_FORCE_LOOP_DBG_NORELOAD", "noreload"), ("NB_FORCE_LOOP_DBG_SERIAL", "serial")):
-            f.write("#define %s \"%s\"\n" % (name, "\\n\\t".join(build_debug(kind))))
+        for v in range(N_VARIANTS):
+            f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(build_variant(v))))
+        f.write("#define NB_FORCE_LOOP_NVARIANTS %d\n" % N_VARIANTS)
+        for k, (pad, group) in enumerate(((1, 16), (3, 16), (9, 16), (1, 8))):
+            f.write("#define NB_FORCE_LOOP_G%d \"%s\"\n" % (k, "\\n\\t".join(build_g16(pad, group))))
+            f.write("#define NB_FORCE_LOOP_G%d_GROUP %d\n" % (k, group))
+        g_regs = ["v%d" % r for r in sorted(set([U] + T2 + [x for d in DSETS for x in d]))] + ["s%d" % r for r in range(36, 100)] + ["scc", "memory"]
+        f.write("#define NB_FORCE_LOOP_G_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in g_regs))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clobbers()))
         f.write("#define NB_FORCE_LOOP_GROUP 8\n")
     n_valu = len([i for i in build_defA(False) if i.startswith("v_")])

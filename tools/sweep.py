@@ -31,14 +31,14 @@ def main():
     pos, vel = nb.make_bodies(n, dtype=np.float64 if args.fp64 else np.float32)
     eng = nb.NBody(n, fp64=args.fp64, tile=args.tile)
     eng.set_option(nb.OPT_TIMING, 1)
-    vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, "isa0": nb.VARIANT_ISA, "isa1": nb.VARIANT_ISA, "isa2": nb.VARIANT_ISA, "isa3": nb.VARIANT_ISA}
+    vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, **{"isa%d" % k: nb.VARIANT_ISA for k in range(30)}}
     res = {c: [] for c in cfgs}
     for rnd in range(args.rounds):
         for c in cfgs:
             v, r, s, w = c
             eng.set_option(nb.OPT_WAVES_PER_SIMD, w)
             eng.set_option(nb.OPT_VARIANT, vmap[v])
-            eng.set_option(nb.OPT_ISA_PHASE, int(v[3]) if v.startswith("isa") else 0)
+            eng.set_option(nb.OPT_ISA_PHASE, int(v[3:]) if v.startswith("isa") else 0)
             eng.set_option(nb.OPT_IBLOCK, r)
             eng.set_option(nb.OPT_JSUB, s)
             eng.upload(pos, vel)
