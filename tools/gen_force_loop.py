@@ -103,6 +103,24 @@ def build_debug(kind):
 
 
 T2 = [20, 24]                       # two d2/inv/inv3 registers (even), alternating with the body index
+# live-in / live-out values are copied to fixed registers too, so that the loop's text (and with it register
+# parity and code bytes) does not depend on hipcc's allocation around the asm statement
+PIN = {"%[xi]": "v8", "%[yi]": "v9", "%[zi]": "v10", "%[ax]": "v12", "%[ay]": "v13", "%[az]": "v14", "%[eps]": "s34"}
+PIN_VGPRS = [8, 9, 10, 12, 13, 14]
+
+
+def pinned(ins):
+    """wrap a loop: copy operands into the pinned registers, rewrite the body, copy the sums back"""
+    head = ["v_mov_b32 v8, %[xi]", "v_mov_b32 v9, %[yi]", "v_mov_b32 v10, %[zi]", "v_mov_b32 v12, %[ax]", "v_mov_b32 v13, %[ay]",
+            "v_mov_b32 v14, %[az]", "s_mov_b32 s34, %[eps]"]
+    body = []
+    for i in ins:
+        for k, v in PIN.items():
+            i = i.replace(k, v)
+        body.append(i)
+    tail = ["v_mov_b32 %[ax], v12", "v_mov_b32 %[ay], v13", "v_mov_b32 %[az], v14"]
+    return head + body + tail
+
 
 
 def body_defA(k, sbase, b):
@@ -179,10 +197,10 @@ def build(phase_nop):
 def build_variant(v):
     """Numbered loops for NBODY_OPT_ISA_PHASE (0/1 are the product phases; >= 2 are bring-up experiments).
     All use the deferred-accumulate order; what differs is how the scalar loads are handled."""
-    if v == 0:
-        return build_defA(False)
-    if v == 1:
-        return build_defA(True)
+    if v == 0:                  # the slow code-placement phase (evidence for DESIGN.md; never the default)
+        return pinned(build_defA(14))
+    if v == 1:                  # THE PRODUCT LOOP: loop head 60 bytes past a 64-byte line
+        return pinned(build_defA(15))
     if 6 <= v < 14:             # placement sweep: loop head at 64-byte line + 4 * (2m + 1) bytes, m = v - 6
         return build_defA(2 * (v - 6) + 1)
     ins = []
@@ -287,9 +305,9 @@ N_VARIANTS = 14
 
 
 def clobbers():
-    regs = ["v%d" % r for r in [T, U] + T2 + [x for d in DSETS for x in d]]
+    regs = ["v%d" % r for r in [T, U] + T2 + PIN_VGPRS + [x for d in DSETS for x in d]]
     regs = sorted(set(regs), key=lambda r: int(r[1:]))
-    regs += ["s%d" % r for r in range(A_BASE, 88)]
+    regs += ["s34"] + ["s%d" % r for r in range(A_BASE, 88)]
     return regs + ["scc", "memory"]
 
 
@@ -306,7 +324,7 @@ def main():
         f.write("#define NB_FORCE_LOOP_G_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in g_regs))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clobbers()))
         f.write("#define NB_FORCE_LOOP_GROUP 8\n")
-    n_valu = len([i for i in build_defA(False) if i.startswith("v_")])
+    n_valu = len([i for i in build_defA(15) if i.startswith("v_")])
     print("wrote %s (%d VALU instructions per group of 8 bodies)" % (OUT, n_valu))
 
 
