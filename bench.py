@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", choices=["ring", "allgather"], default="ring")
+    ap.add_argument("--comm", choices=["auto", "ring", "allgather"], default="auto")
+    ap.add_argument("--transport", choices=["auto", "rccl", "host"], default="auto")
     ap.add_argument("--no-overlap", action="store_true")
     args = ap.parse_args()
 
@@ -113,14 +114,14 @@ def main():
             dist.barrier()
 
     n = args.n
-    eng = D.make_engine(n, fp64=args.fp64, tile=args.tile)
+    eng = D.make_engine(n, fp64=args.fp64, tile=args.tile, transport=args.transport)
     eng.set_option(nb.OPT_VARIANT, {"auto": nb.VARIANT_AUTO, "smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS,
                                     "readlane": nb.VARIANT_READLANE, "isa": nb.VARIANT_ISA}[args.variant])
     if args.isa_phase >= 0:
         eng.set_option(nb.OPT_ISA_PHASE, args.isa_phase)
     eng.set_option(nb.OPT_IBLOCK, args.iblock)
     eng.set_option(nb.OPT_JSUB, args.jsub)
-    eng.set_option(nb.OPT_COMM, nb.COMM_ALLGATHER if args.comm == "allgather" else nb.COMM_RING)
+    eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER}[args.comm])
     eng.set_option(nb.OPT_OVERLAP, 0 if args.no_overlap else 1)
     import numpy as np
     pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
@@ -175,7 +176,7 @@ def main():
             "config": {"workload": "N=%d %s all-pairs softened gravity, leapfrog kick-drift, dt=0.01, seed %d"
                                    % (n, "fp64" if args.fp64 else "fp32", args.seed),
                        "n_bodies": n, "pairs_per_step": pairs_per_step, "parallelism": "bodies sharded over %d GPU(s)" % world,
-                       "kernel": cfg, "comm": args.comm if world > 1 else None, "finite": finite},
+                       "kernel": cfg, "comm": (args.comm + " / " + getattr(eng, "transport", "rccl")) if world > 1 else None, "finite": finite},
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 2), "peak": PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
                          "flop_per_pair": FLOP_PER_PAIR, "kernel_ms_avg": round(avg_launch_s * 1e3, 4),

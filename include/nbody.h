@@ -74,7 +74,8 @@ enum { NBODY_ARITH_FMA3 = 0,       /* d2 = fma(dx,dx,fma(dy,dy,fma(dz,dz,eps))):
 enum { NBODY_SUM_SEQ = 0,          /* one accumulator per segment, sources ascending (S/top_level.vhd:233-254) */
        NBODY_SUM_FPGA16 = 1        /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */ };
 enum { NBODY_COMM_RING = 0,        /* P-1 ncclSend/ncclRecv ring steps, one event per arriving slice */
-       NBODY_COMM_ALLGATHER = 1    /* one in-place ncclAllGather */ };
+       NBODY_COMM_ALLGATHER = 1,   /* one in-place ncclAllGather (needs N divisible by the rank count, else ring) */
+       NBODY_COMM_AUTO = 2         /* default: ALLGATHER when N divides evenly, RING otherwise */ };
 
 /* ---- info keys (nbody_get_info) ---- */
 enum { NBODY_INFO_N = 1, NBODY_INFO_N_LOCAL, NBODY_INFO_FIRST_BODY, NBODY_INFO_RANK, NBODY_INFO_NRANKS,
@@ -136,6 +137,14 @@ int nbody_forces_rows(int first_row, int n_rows, float *force_words);
  * BEGIN = 0 and bits 63:32 = elapsed time in units of 1000 clocks of `clock_khz` (0: 300 MHz),
  * as S/top_level.vhd:121-146 counts them.  Returns NBODY_ERR_STATE if BEGIN is not set. */
 int nbody_mailbox_run(void *ram_a, void *ram_b, int clock_khz);
+
+/* Multi-process transport without RCCL: call nbody_init_rank(..., uid128 = NULL), then register a function that
+ * all-gathers a host array in place: on entry host_words[first..first+count) of this rank are valid (words of word_bytes
+ * bytes, slices as nbody_get_info FIRST_BODY / N_LOCAL), on return all n_total words must be.  Returns 0 on success.
+ * Slower (PCIe + the host framework's collective) but needs nothing from the GPU fabric; also what the two-process
+ * GPU test uses on a one-GPU box. */
+typedef int (*nbody_host_gather_fn)(void *user, void *host_words, int n_total, int word_bytes, int rank, int nranks);
+int nbody_set_host_gather(nbody_host_gather_fn fn, void *user);
 
 /* Sum of HIP-event durations of the force kernels since the last reset (NBODY_OPT_TIMING = 1). */
 int nbody_kernel_time(double *ms_total, long long *launches, int reset);

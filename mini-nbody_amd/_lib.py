@@ -14,7 +14,7 @@ OPT_VARIANT, OPT_IBLOCK, OPT_JSUB, OPT_JSLICES, OPT_ARITH, OPT_SUM_ORDER, OPT_TI
 VARIANT_AUTO, VARIANT_SMEM, VARIANT_LDS, VARIANT_READLANE, VARIANT_ISA = range(5)
 ARITH_FMA3, ARITH_REFERENCE, ARITH_STRICT, ARITH_REFERENCE_STRICT = 0, 1, 2, 3
 SUM_SEQ, SUM_FPGA16 = 0, 1
-COMM_RING, COMM_ALLGATHER = 0, 1
+COMM_RING, COMM_ALLGATHER, COMM_AUTO = 0, 1, 2
 (INFO_N, INFO_N_LOCAL, INFO_FIRST_BODY, INFO_RANK, INFO_NRANKS, INFO_VARIANT, INFO_IBLOCK, INFO_JSUB, INFO_NSEG,
  INFO_DEVICE, INFO_CU_COUNT, INFO_CLOCK_KHZ, INFO_FP64, INFO_TILE, INFO_STEPS_DONE) = range(1, 16)
 
@@ -26,7 +26,11 @@ SYMBOLS = [
     "nbody_error_string", "nbody_upload", "nbody_download", "nbody_upload_d", "nbody_download_d", "bodyForce",
     "integrate", "bodyForce_d", "integrate_d", "nbody_step", "nbody_step_d", "nbody_sync", "nbody_forces",
     "nbody_forces_d", "nbody_forces_rows", "nbody_mailbox_run", "nbody_kernel_time", "nbody_device_ptr",
+    "nbody_set_host_gather",
 ]
+
+
+HOST_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
 
 
 class BodySystem(C.Structure):
@@ -65,6 +69,7 @@ def load():
         "nbody_forces": [fp, fp, i], "nbody_forces_d": [dp, dp, i], "nbody_forces_rows": [i, i, fp],
         "nbody_mailbox_run": [vp, vp, i], "nbody_kernel_time": [C.POINTER(d), C.POINTER(C.c_longlong), i],
         "nbody_device_ptr": [i, C.POINTER(vp), C.POINTER(C.c_size_t)],
+        "nbody_set_host_gather": [HOST_GATHER_FN, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

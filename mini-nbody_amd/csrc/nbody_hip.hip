@@ -98,10 +98,15 @@ struct Local {
 
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
-  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_RING, overlap = 1, isa_phase = 1, waves_per_simd = 0;
+  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0;
 };
 
+typedef int (*host_gather_fn)(void* user, void* host_words, int n_total, int word_bytes, int rank, int nranks);
+
 struct Global {
+  host_gather_fn host_gather = nullptr;   // multi-process fallback transport: slices exchanged through host memory
+  void* host_gather_user = nullptr;
+  void* host_stage = nullptr;             // pinned staging buffer, N words
   bool init = false;
   int n = 0, fp64 = 0, tile = 256;
   int nranks = 1, nlocal = 0;
@@ -345,6 +350,22 @@ int launch_combine(Local& L, int row0, int row_count, bool kick, bool drift, boo
 
 inline int ring_slice(int rank, int s) { int q = (rank - s) % g.nranks; return q < 0 ? q + g.nranks : q; }
 
+// Host-staged all-gather of one sharded device array (words [first, first+count) are this rank's): D2H own part,
+// callback (the host framework's all-gather fills the rest of g.host_stage), H2D everything else on the comm stream.
+int host_exchange(Local& L, void* dev_full, int first, int count, bool wait_own_ready) {
+  const size_t wb = word_bytes();
+  if (!g.host_stage) HIPC(hipHostMalloc(&g.host_stage, (size_t)(g.n + 64) * 32, hipHostMallocDefault));
+  if (wait_own_ready) HIPC(hipEventSynchronize(L.ev_own_ready));
+  HIPC(hipMemcpy(word_ptr(g.host_stage, first), word_ptr(dev_full, first), (size_t)count * wb, hipMemcpyDeviceToHost));
+  int rc = g.host_gather(g.host_gather_user, g.host_stage, g.n, (int)wb, L.rank, g.nranks);
+  if (rc) return NBODY_ERR_STATE;
+  if (first > 0) HIPC(hipMemcpyAsync(dev_full, g.host_stage, (size_t)first * wb, hipMemcpyHostToDevice, L.comm));
+  const int after = first + count;
+  if (after < g.n)
+    HIPC(hipMemcpyAsync(word_ptr(dev_full, after), word_ptr(g.host_stage, after), (size_t)(g.n - after) * wb, hipMemcpyHostToDevice, L.comm));
+  return NBODY_OK;
+}
+
 // Bring the other ranks' slices of pos[buf] to every local.  Enqueued on the comm streams; records
 // ev_gather[s] (s = 1..P-1) as slices arrive.  Sources are valid after their owner's ev_own_ready.
 int enqueue_gather(int buf) {
@@ -369,9 +390,16 @@ int enqueue_gather(int buf) {
   }
   Local& L = g.loc[0];
   HIPC(hipSetDevice(L.device));
+  if (!g.host_gather && !L.comm_h) return NBODY_ERR_STATE;   // neither RCCL nor a host transport was set up
+  if (g.host_gather) {
+    // host-staged transport (no RCCL): own slice down, exchange on the host, the other slices up
+    NBC(host_exchange(L, L.pos[buf], L.first, L.n_local, true));
+    for (int s = 1; s < P; ++s) HIPC(hipEventRecord(L.ev_gather[s], L.comm));
+    return NBODY_OK;
+  }
   HIPC(hipStreamWaitEvent(L.comm, L.ev_own_ready, 0));
   const bool even = (g.n % P) == 0;
-  if (g.opt.comm == NBODY_COMM_ALLGATHER && even) {
+  if (even && (g.opt.comm == NBODY_COMM_ALLGATHER || g.opt.comm == NBODY_COMM_AUTO)) {
     NCCLC(g_rccl.AllGather(word_ptr(L.pos[buf], L.first), L.pos[buf], (size_t)L.n_local * wb, ncclChar, L.comm_h, L.comm));
     for (int s = 1; s < P; ++s) HIPC(hipEventRecord(L.ev_gather[s], L.comm));
     return NBODY_OK;
@@ -396,7 +424,11 @@ int enqueue_step(float dt, double dt64) {
   const int P = g.nranks;
   const bool fused = (g.nseg == 1);
   const bool need_gather = !g.loc[0].all_present;
-  if (need_gather && g.opt.overlap) NBC(enqueue_gather(g.loc[0].cur));
+  if (need_gather && g.opt.overlap) {
+    // own slice first: these kernels run while the other slices travel (second stream / host-staged exchange)
+    for (int l = 0; l < g.nlocal; ++l) NBC(launch_force(g.loc[l], 0, g.loc[l].n_local, g.loc[l].rank, 1, false, dt, dt64));
+    NBC(enqueue_gather(g.loc[0].cur));
+  }
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
     HIPC(hipSetDevice(L.device));
@@ -409,9 +441,8 @@ int enqueue_step(float dt, double dt64) {
     } else if (!need_gather) {
       NBC(launch_force(L, 0, L.n_local, L.rank, P, false, dt, dt64));
     } else if (g.opt.overlap) {
-      // own slice now; the others as they arrive (one launch for all of them after the last event:
-      // the transfer is ~100 us against milliseconds of own-slice work)
-      NBC(launch_force(L, 0, L.n_local, L.rank, 1, false, dt, dt64));
+      // the other slices once they have all arrived (one launch: the transfer is ~100 us against
+      // milliseconds of own-slice work already running)
       HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[P - 1], 0));
       NBC(launch_force(L, 0, L.n_local, ring_slice(L.rank, 1), P - 1, false, dt, dt64));
     } else {
@@ -522,6 +553,12 @@ int gather_vel_multiprocess(Local& L) {
   HIPC(hipSetDevice(L.device));
   if (!L.vel_full) HIPC(hipMalloc(&L.vel_full, (size_t)(g.n + 64) * wb));
   HIPC(hipMemcpyAsync(word_ptr(L.vel_full, L.first), L.vel, (size_t)L.n_local * wb, hipMemcpyDeviceToDevice, L.comm));
+  if (g.host_gather) {
+    HIPC(hipStreamSynchronize(L.comm));
+    NBC(host_exchange(L, L.vel_full, L.first, L.n_local, false));
+    HIPC(hipStreamSynchronize(L.comm));
+    return NBODY_OK;
+  }
   const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
   for (int s = 1; s < P; ++s) {
     const int qs = ring_slice(L.rank, s - 1), qr = ring_slice(L.rank, s);
@@ -721,8 +758,7 @@ int nbody_unique_id(void* uid128) {
 int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void* uid128) {
   if (g.init) nbody_shutdown();
   if (nranks <= 0 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return NBODY_ERR_ARG;
-  if (nranks > 1 && !uid128) return NBODY_ERR_ARG;
-  NBC(init_common(n, fp64, tile));
+  NBC(init_common(n, fp64, tile));   // uid128 == NULL with nranks > 1: no RCCL, nbody_set_host_gather() must follow
   if (n < nranks) return NBODY_ERR_ARG;
   int ndev = 0;
   NBC(device_count(&ndev));
@@ -738,7 +774,7 @@ int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void*
   hipDeviceProp_t prop;
   HIPC(hipGetDeviceProperties(&prop, L.device));
   g.cu_count = prop.multiProcessorCount; g.clock_khz = prop.clockRate;
-  if (nranks > 1) {
+  if (nranks > 1 && uid128) {
     e = rccl_load();
     if (e) { nbody_shutdown(); return e; }
     ncclUniqueId id;
@@ -756,6 +792,8 @@ int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void*
 
 void nbody_shutdown(void) {
   for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);
+  if (g.host_stage) { (void)hipHostFree(g.host_stage); g.host_stage = nullptr; }
+  g.host_gather = nullptr; g.host_gather_user = nullptr;
   g.init = false; g.nlocal = 0; g.nranks = 1; g.partial_words = 0;
 }
 
@@ -768,7 +806,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_ARITH: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.arith = value; break;
     case NBODY_OPT_SUM_ORDER: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.sum_order = value; break;
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
-    case NBODY_OPT_COMM: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.comm = value; break;
+    case NBODY_OPT_COMM: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: g.opt.overlap = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
     case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 23) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
@@ -874,6 +912,14 @@ int nbody_mailbox_run(void* ram_a, void* ram_b, int clock_khz) {
   const double khz = clock_khz > 0 ? (double)clock_khz : 300000.0;
   uint32_t ticks = 1u + (uint32_t)((double)ms * khz / 1000.0);
   w0[0] = 0; w0[1] = ticks; w0[2] = 0; w0[3] = 0;
+  return NBODY_OK;
+}
+
+int nbody_set_host_gather(nbody_host_gather_fn fn, void* user) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!g.multiprocess) return NBODY_ERR_STATE;
+  g.host_gather = (host_gather_fn)fn;
+  g.host_gather_user = user;
   return NBODY_OK;
 }
 

@@ -34,11 +34,56 @@ def broadcast_unique_id(make_uid):
     return box[0]
 
 
-def make_engine(n, fp64=False, tile=0):
-    """NBody engine for this process: single GPU when WORLD_SIZE is 1, else rank `RANK` of the job."""
+def gloo_host_gather(host_ptr, n_total, word_bytes, rank, nranks):
+    """All-gather of a sharded host array through torch.distributed (any backend that moves CPU tensors)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from .sharding import slice_bounds
+    buf = np.ctypeslib.as_array((C.c_ubyte * (n_total * word_bytes)).from_address(host_ptr))
+    maxlen = (-(-n_total // nranks)) * word_bytes
+    f0, f1 = slice_bounds(rank, n_total, nranks)
+    mine = torch.zeros(maxlen, dtype=torch.uint8)
+    mine[:(f1 - f0) * word_bytes] = torch.from_numpy(buf[f0 * word_bytes:f1 * word_bytes].copy())
+    outs = [torch.empty(maxlen, dtype=torch.uint8) for _ in range(nranks)]
+    dist.all_gather(outs, mine)
+    for q in range(nranks):
+        if q == rank:
+            continue
+        b0, b1 = slice_bounds(q, n_total, nranks)
+        buf[b0 * word_bytes:b1 * word_bytes] = outs[q][:(b1 - b0) * word_bytes].numpy()
+    return 0
+
+
+def make_engine(n, fp64=False, tile=0, transport="auto"):
+    """NBody engine for this process: single GPU when WORLD_SIZE is 1, else rank `RANK` of the job.
+    transport: "rccl" (positions travel GPU to GPU inside the library), "host" (staged through host memory and
+    torch.distributed), "auto" (rccl, and if any rank cannot set it up, every rank falls back to host)."""
+    import torch
+    import torch.distributed as dist
     from .engine import NBody, unique_id
+    from ._lib import NBodyError
     rank, world, _ = env_rank()
     if world == 1:
         return NBody(n, fp64=fp64, tile=tile)
-    uid = broadcast_unique_id(unique_id)
-    return NBody(n, fp64=fp64, tile=tile, rank=rank, nranks=world, uid=uid)
+    eng, err = None, ""
+    if transport in ("auto", "rccl"):
+        try:
+            uid = broadcast_unique_id(unique_id)
+            eng = NBody(n, fp64=fp64, tile=tile, rank=rank, nranks=world, uid=uid)
+        except (NBodyError, OSError) as e:
+            eng, err = None, str(e)
+            if transport == "rccl":
+                raise
+        ok = torch.tensor([1 if eng is not None else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 1:
+            eng.transport = "rccl"
+            return eng
+        if eng is not None:
+            eng.close()
+    eng = NBody(n, fp64=fp64, tile=tile, rank=rank, nranks=world, uid=None)
+    eng.set_host_gather(gloo_host_gather)
+    eng.transport = "host-staged via torch.distributed" + (" (RCCL unavailable: %s)" % err if err else "")
+    return eng

@@ -121,6 +121,19 @@ class NBody:
         L.check(self.lib.nbody_device_ptr(int(which), C.byref(p), C.byref(b)))
         return p.value, b.value
 
+    def set_host_gather(self, fn):
+        """Multi-process transport through host memory: fn(host_ptr, n_total, word_bytes, rank, nranks) -> 0 must
+        all-gather the array in place (see nbody_set_host_gather in include/nbody.h)."""
+        def tramp(user, host_ptr, n_total, word_bytes, rank, nranks):
+            try:
+                return int(fn(host_ptr, n_total, word_bytes, rank, nranks) or 0)
+            except Exception:   # an exception must not unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._gather_cb = L.HOST_GATHER_FN(tramp)      # keep the thunk alive as long as the engine
+        L.check(self.lib.nbody_set_host_gather(self._gather_cb, None))
+
     def close(self):
         if self._open:
             self.lib.nbody_shutdown()
