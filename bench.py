@@ -60,7 +60,7 @@ def cpu_baseline(n, seed):
     ora.forces_f32(pos[:rows], pos, rsqrt=O.RSQRT_DIVSQRT)
     t = time.perf_counter() - t0
     rate = rows * n / t
-    target_s = 12.0
+    target_s = 20.0
     rows2 = int(min(n, max(rows, (rate * target_s / n) // 16 * 16)))
     if rows2 > rows:
         t0 = time.perf_counter()
