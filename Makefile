@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-s
 all: lib host oracle microbench
 
 lib: $(PKG)/libnbody_hip.so
-$(PKG)/libnbody_hip.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp include/nbody.h
+$(PKG)/libnbody_hip.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/force_loop_gfx950.inc include/nbody.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/nbody_hip.hip -ldl
 
 # C host program (north_star: "host code stays in C"): links only the C-ABI
@@ -24,10 +24,18 @@ build/nbody: $(PKG)/host/nbody.c include/nbody.h include/nbody_ic.h $(PKG)/libnb
 oracle:
 	$(MAKE) -C oracle
 
-microbench: build/microbench
+microbench: build/microbench build/microbench_streams
 build/microbench: $(CSRC)/microbench.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+build/microbench_streams: $(CSRC)/microbench_streams.hip $(CSRC)/microbench_streams.inc
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
+# generated sources (committed): the hand-scheduled loop and the microbenchmark streams
+gen:
+	python3 tools/gen_force_loop.py
+	python3 tools/gen_streams.py
 
 isa: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp
 	@mkdir -p build/isa
@@ -37,4 +45,4 @@ clean:
 	rm -rf build $(PKG)/libnbody_hip.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib host oracle microbench isa clean
+.PHONY: all lib host oracle microbench isa gen clean

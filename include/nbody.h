@@ -57,8 +57,8 @@ enum {
   NBODY_OPT_COMM = 8,      /* NBODY_COMM_* (multi-GPU) */
   NBODY_OPT_OVERLAP = 9,   /* multi-GPU: 1 = start on the rank's own slice while the others travel (default), 0 = gather first */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
-  NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: which generated loop (tools/gen_force_loop.py): 1 = product (default), 0 = the slow
-                              code-placement phase, 2.. = bring-up experiments (some are timing-only: wrong results) */
+  NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: 1 = the product loop (default), 0 = the same instructions placed one 4-byte
+                              phase off — 27 % slower, kept so that the code-placement effect can be re-measured */
 };
 enum { NBODY_VARIANT_AUTO = 0,     /* ISA for the timed arithmetic (fp32, FMA3, sequential sum), else SMEM */
        NBODY_VARIANT_SMEM = 1,     /* wave-uniform scalar loads (s_load_dwordx16) into SGPRs: no LDS, no VALU cost */

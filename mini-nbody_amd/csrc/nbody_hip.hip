@@ -300,26 +300,7 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, bo
     }
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
-    switch (g.opt.isa_phase) {
-      case 1: return launch_timed(L, force_isa_f32<1>, grid, a);
-      case 2: return launch_timed(L, force_isa_f32<2>, grid, a);
-      case 3: return launch_timed(L, force_isa_f32<3>, grid, a);
-      case 4: return launch_timed(L, force_isa_f32<4>, grid, a);
-      case 5: return launch_timed(L, force_isa_f32<5>, grid, a);
-      case 6: return launch_timed(L, force_isa_f32<6>, grid, a);
-      case 7: return launch_timed(L, force_isa_f32<7>, grid, a);
-      case 8: return launch_timed(L, force_isa_f32<8>, grid, a);
-      case 9: return launch_timed(L, force_isa_f32<9>, grid, a);
-      case 10: return launch_timed(L, force_isa_f32<10>, grid, a);
-      case 11: return launch_timed(L, force_isa_f32<11>, grid, a);
-      case 12: return launch_timed(L, force_isa_f32<12>, grid, a);
-      case 13: return launch_timed(L, force_isa_f32<13>, grid, a);
-      case 20: return launch_timed(L, force_isa_f32<20>, grid, a);
-      case 21: return launch_timed(L, force_isa_f32<21>, grid, a);
-      case 22: return launch_timed(L, force_isa_f32<22>, grid, a);
-      case 23: return launch_timed(L, force_isa_f32<23>, grid, a);
-      default: return launch_timed(L, force_isa_f32<0>, grid, a);
-    }
+    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0>, grid, a) : launch_timed(L, force_isa_f32<1>, grid, a);
   }
   switch (R) {
     case 1: return launch_f32_R<1>(L, grid, a);
@@ -809,7 +790,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_COMM: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: g.opt.overlap = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
-    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 23) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
+    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); return reconfigure(); }

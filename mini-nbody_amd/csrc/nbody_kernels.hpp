@@ -239,12 +239,13 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// ISA variant: the SMEM kernel with its inner loop written instruction by instruction
-// (force_loop_gfx950.inc, generated by tools/gen_force_loop.py, which explains the three hardware
-// facts it is built on).  One body per lane; same arithmetic, same order, same bits as
-// force_smem_f32<1, 0>.  PHASE selects the 4-byte phase at which the loop's 64-bit encodings start.
+// ISA variant (the default for the timed arithmetic): scalar delivery as in force_smem_f32, with the inner loop
+// written instruction by instruction (force_loop_gfx950.inc, generated by tools/gen_force_loop.py, which
+// explains the hardware facts it is built on).  One body per lane; same arithmetic, same order and hence the
+// same bits as force_smem_f32<1, 0>.  PLACEMENT = 1 is the product loop, 0 the same instructions one 4-byte
+// phase off (kept to re-measure the code-placement effect).
 #include "force_loop_gfx950.inc"
-template <int PHASE>
+template <int PLACEMENT>
 __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
@@ -256,41 +257,23 @@ __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
   const float xi = me.x, yi = me.y, zi = me.z;
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
   int j = jb;
-  if constexpr (PHASE >= 20) {
-    // 16-/8-body groups, base + offset addressing, fused count-down (tools/gen_force_loop.py build_g16)
-    constexpr int GROUP = PHASE == 23 ? NB_FORCE_LOOP_G3_GROUP : NB_FORCE_LOOP_G0_GROUP;
-    const int groups = (je - jb) / GROUP;
-    if (groups > 0) {
-      const uint64_t p = (uint64_t)(uintptr_t)a.src;
-      unsigned off = (unsigned)jb * (unsigned)sizeof(f4);
-      unsigned cnt = (unsigned)groups - 1u;
-#define NB_RUN_G(K)                                                                                            \
-      if constexpr (PHASE == 20 + K) {                                                                         \
-        asm volatile(NB_FORCE_LOOP_G##K                                                                        \
-                     : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [off] "+s"(off), [cnt] "+s"(cnt)          \
-                     : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p)                    \
-                     : NB_FORCE_LOOP_G_CLOBBERS);                                                              \
-      }
-      NB_RUN_G(0) NB_RUN_G(1) NB_RUN_G(2) NB_RUN_G(3)
-#undef NB_RUN_G
-      j += groups * GROUP;
-    }
-  }
-  const int groups = PHASE >= 20 ? 0 : (je - jb) / NB_FORCE_LOOP_GROUP;
+  const int groups = (je - jb) / NB_FORCE_LOOP_GROUP;
   if (groups > 0) {
     const uint64_t p = (uint64_t)(uintptr_t)a.src + (uint64_t)jb * sizeof(f4);
-#define NB_RUN_LOOP(V)                                                                                         \
-    if constexpr (PHASE == V) {                                                                                \
-      asm volatile(NB_FORCE_LOOP_V##V                                                                          \
-                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)                                               \
-                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups) \
-                   : NB_FORCE_LOOP_CLOBBERS);                                                                  \
+    if constexpr (PLACEMENT == 1) {
+      asm volatile(NB_FORCE_LOOP_V1
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_CLOBBERS);
+    } else {
+      asm volatile(NB_FORCE_LOOP_V0
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_CLOBBERS);
     }
-    NB_RUN_LOOP(0) NB_RUN_LOOP(1) NB_RUN_LOOP(2) NB_RUN_LOOP(3) NB_RUN_LOOP(4) NB_RUN_LOOP(5) NB_RUN_LOOP(6) NB_RUN_LOOP(7)
-    NB_RUN_LOOP(8) NB_RUN_LOOP(9) NB_RUN_LOOP(10) NB_RUN_LOOP(11) NB_RUN_LOOP(12) NB_RUN_LOOP(13)
-#undef NB_RUN_LOOP
     j += groups * NB_FORCE_LOOP_GROUP;
   }
+  // the (< 8) sources left over, with the compiled pair function: identical operations
   const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
   for (; j < je; ++j) {
     f4 q = src[j];

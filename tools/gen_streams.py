@@ -423,23 +423,13 @@ _gfl = _ilu.module_from_spec(_spec)
 _spec.loader.exec_module(_gfl)
 
 
-def _real(ins):
-    return [i.replace("%[xi]", "v0").replace("%[yi]", "v1").replace("%[zi]", "v2").replace("%[ax]", "v4").replace("%[ay]", "v5")
-             .replace("%[az]", "v6").replace("%[eps]", "s23") for i in ins]
-
-
-body = _real(_gfl.half(36, ["s_nop 0", "s_nop 0"]) + _gfl.half(52, ["s_nop 0", "s_nop 0"]))
+body = []
+for _k in range(8):
+    body += _gfl.body(_k, 36 if _k < 4 else 52, _k & 3)
 for k in (0, 1):
     pre = [".p2align 6"] + ["s_nop 0"] * k
-    streams.append(("real_loop_k%d" % k, "the ISA kernel's loop body (96 VALU, s36..s67 sources), phase %d" % k, body,
+    streams.append(("real_loop_k%d" % k, "the ISA kernel's loop body (96 VALU, s36..s67 sources, pinned registers), phase %d" % k, body,
                     len([i for i in body if i.startswith("v_")]), sorted(set(vregs(body)), key=lambda r: int(r[1:])), pre))
-# same but every body reads the same three SGPRs
-body2 = [__import__("re").sub(r"\bs(3[6-9]|[45][0-9]|6[0-7])\b", lambda m: "s%d" % (20 + (int(m.group(1)) % 4) % 3), i) for i in body]
-for k in (0, 1):
-    pre = [".p2align 6"] + ["s_nop 0"] * k
-    streams.append(("real_loop_sameS_k%d" % k, "same, all bodies read s20..s22, phase %d" % k, body2,
-                    len([i for i in body2 if i.startswith("v_")]), sorted(set(vregs(body2)), key=lambda r: int(r[1:])), pre))
-
 
 
 # ---- legal orderings of the single-chain pair stream (>= 1 instruction between v_rsq_f32 and its consumer)
@@ -498,7 +488,7 @@ def main():
             # well-conditioned operands: every VGPR 0.5 (+ a little per register), the SGPR sources 0.25 / -0.125 / 0.75
             init = ["v_mov_b32 %s, 0x%08x" % (r, 0x3F000000 + 4096 * int(r[1:])) for r in regs]
             init += ["s_mov_b32 s20, 0.25", "s_mov_b32 s21, 0xbe000000", "s_mov_b32 s22, 0x3f400000", "s_mov_b32 s23, 0x3089705f"]
-            init += ["s_mov_b32 s%d, 0x%08x" % (r, 0x3E000000 + 65536 * r) for r in range(36, 68)]
+            init += ["s_mov_b32 s%d, 0x%08x" % (r, 0x3E000000 + 65536 * r) for r in range(36, 68)] + ["s_mov_b32 s34, 0x3089705f"]
             itext = "\\n\\t".join(init)
             ptext = "\\n\\t".join(pre)
             f.write("STREAM(%s, \"%s\", %d, \"%s\", \"%s\", \"%s\", %s)\n" % (name, desc, n, text, itext, ptext, clob))
