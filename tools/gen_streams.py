@@ -432,6 +432,23 @@ for k in (0, 1):
                     len([i for i in body if i.startswith("v_")]), sorted(set(vregs(body)), key=lambda r: int(r[1:])), pre))
 
 
+# the same loop WITH its scalar loads and waits (sources read from the kernarg segment, s[0:1]: garbage values, timing only)
+body_ld = (["s_waitcnt lgkmcnt(0)", "s_nop 0", "s_load_dwordx16 s[52:67], s[0:1], 0x0"] + body[:48] + ["s_nop 0", "s_nop 0"] +
+           ["s_waitcnt lgkmcnt(0)", "s_nop 0", "s_load_dwordx16 s[36:51], s[0:1], 0x0"] + body[48:])
+streams.append(("real_loop_loads_k0", "the ISA kernel's loop body + its two s_load_dwordx16 and waits per 8 bodies", body_ld,
+                len([i for i in body_ld if i.startswith("v_")]), sorted(set(vregs(body_ld)), key=lambda r: int(r[1:])), [".p2align 6"]))
+# loads only, no waits (the SGPRs are overwritten while being read: timing only)
+body_ld2 = (["s_nop 0", "s_nop 0", "s_load_dwordx16 s[52:67], s[0:1], 0x0"] + body[:48] + ["s_nop 0", "s_nop 0"] +
+            ["s_nop 0", "s_nop 0", "s_load_dwordx16 s[36:51], s[0:1], 0x0"] + body[48:])
+streams.append(("real_loop_loadsnowait_k0", "same without the waits", body_ld2,
+                len([i for i in body_ld2 if i.startswith("v_")]), sorted(set(vregs(body_ld2)), key=lambda r: int(r[1:])), [".p2align 6"]))
+# loads into SGPRs nothing reads
+body_ld3 = (["s_waitcnt lgkmcnt(0)", "s_nop 0", "s_load_dwordx16 s[72:87], s[0:1], 0x0"] + body[:48] + ["s_nop 0", "s_nop 0"] +
+            ["s_waitcnt lgkmcnt(0)", "s_nop 0", "s_load_dwordx16 s[72:87], s[0:1], 0x0"] + body[48:])
+streams.append(("real_loop_loadsscratch_k0", "same, loads land in SGPRs nothing reads", body_ld3,
+                len([i for i in body_ld3 if i.startswith("v_")]), sorted(set(vregs(body_ld3)), key=lambda r: int(r[1:])), [".p2align 6"]))
+
+
 # ---- legal orderings of the single-chain pair stream (>= 1 instruction between v_rsq_f32 and its consumer)
 TT = [20, 24]; UU = 22; DD = [(21, 23, 25), (27, 29, 31)]
 
