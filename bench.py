@@ -161,13 +161,20 @@ def main():
         achieved_tflops = kernel_rate * FLOP_PER_PAIR / 1e12
         cu, clk = eng.info(nb._lib.INFO_CU_COUNT), eng.info(nb._lib.INFO_CLOCK_KHZ) * 1e3
         issue_bound = cu * 4 * 64.0 / ISSUE_CYCLES_PER_WAVE_PAIR * clk   # pairs/s at the nominal clock
-        traffic = None
+        # PMC figures come from the committed rocprofv3 passes of this same command (profiles/latest_pmc.json,
+        # tools/profile.sh): counters cannot be read from inside the timed process
+        traffic, pmc_extra = None, {}
         pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
         if os.path.exists(pmc) and not args.fp64 and n == (1 << 20) and world == 1:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                pmc_extra = {"valu_busy_frac_pmc": round(pj.get("valu_busy_frac", 0.0), 4),
+                             "clock_ghz_pmc": round(pj.get("clock_ghz", 0.0), 3),
+                             "hbm_gb_per_s_pmc": round(pj.get("hbm_gb_per_s", 0.0), 2),
+                             "hbm_frac_of_peak_pmc": round(pj.get("hbm_frac_of_8tbs", 0.0), 5)}
             except Exception:
-                traffic = None
+                traffic, pmc_extra = None, {}
         out = {
             "metric": "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofline",
             "value": round(value, 2), "unit": "billion pair-interactions/s", "n_gpus": world, "steps": args.steps,
@@ -182,7 +189,7 @@ def main():
                          "flop_per_pair": FLOP_PER_PAIR, "kernel_ms_avg": round(avg_launch_s * 1e3, 4),
                          "kernel_launches": launches, "kernel_gpairs_per_s": round(kernel_rate / 1e9, 1),
                          "issue_bound_gpairs_per_s": round(issue_bound / 1e9, 1),
-                         "frac_of_issue_bound": round(kernel_rate / issue_bound, 4) if issue_bound else None,
+                         "frac_of_issue_bound": round(kernel_rate / issue_bound, 4) if issue_bound else None, **pmc_extra,
                          "note": "VALU-issue-bound (11 full-rate + 1 quarter-rate op per pair = 30 cycles per wave64); "
                                  "the fp32 MFMA peak is the same 157.3 TFLOP/s but the path has no contraction to put on it"},
         }

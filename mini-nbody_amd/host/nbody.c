@@ -6,7 +6,7 @@
  * with the first iteration excluded as warm-up, and the metric of BASELINE.md
  * §2: billion pair-interactions/s = N^2 * timed_steps / seconds / 1e9.
  *
- * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict]
+ * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -26,24 +26,26 @@ static double now_s(void) {
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s failed: %s\n", #call, nbody_error_string(rc_)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0;
+  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0;
   unsigned long long seed = NBODY_IC_DEFAULT_SEED;
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--tile") && a + 1 < argc) tile = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--jsub") && a + 1 < argc) jsub = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--seed") && a + 1 < argc) seed = strtoull(argv[++a], NULL, 10);
     else if (!strcmp(argv[a], "--fp64")) fp64 = 1;
     else if (!strcmp(argv[a], "--host-loop")) host_loop = 1;
     else if (!strcmp(argv[a], "--strict")) strict = 1;
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   const float dt = 0.01f;
   const size_t words = (size_t)n * 4;
   CHECK(nbody_init(n, gpus, fp64, tile));
-  if (strict) CHECK(nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_STRICT));
+  if (strict) CHECK(nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_STRICT));   /* IEEE-exact: bit-identical to the CPU oracle */
+  if (jsub > 0) CHECK(nbody_set_option(NBODY_OPT_JSUB, jsub));                 /* source segments (summation order) */
 
   double total = 0.0;
   if (!fp64) {

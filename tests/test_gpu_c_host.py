@@ -1,0 +1,31 @@
+"""The C host program (mini-nbody_amd/host/nbody.c: plain C over the C-ABI) end to end on the GPU: its checksum of
+positions after 10 strict-mode iterations must equal the oracle's, for the host-pointer bodyForce()/integrate() loop
+and for the device-resident loop."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "build", "nbody")
+
+
+@pytest.mark.parametrize("extra", [["--host-loop"], []])
+def test_c_host_program_matches_oracle(nb, oracle_fast, extra):
+    if not os.path.exists(EXE):
+        pytest.fail("build/nbody is missing: run `make host`")
+    n, iters = 4096, 10
+    env = dict(os.environ, NBODY_JSUB="1")
+    out = subprocess.run([EXE, str(n), str(iters), "--strict", "--jsub", "1"] + extra, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"checksum \(sum of positions\): (\S+) (\S+) (\S+)", out.stdout)
+    assert m, out.stdout
+    got = np.array([float(m.group(k)) for k in (1, 2, 3)])
+    pos, vel = nb.make_bodies(n)
+    oracle_fast.step(pos, vel, 0.01, iters)
+    want = pos[:, :3].astype(np.float64).sum(0)
+    assert np.allclose(got, want, rtol=0, atol=1e-6 * np.abs(pos[:, :3]).sum()), (got, want)   # printed with %.9g
+    assert re.search(r"%d Bodies .* Billion Interactions / second" % n, out.stdout)

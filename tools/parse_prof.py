@@ -49,6 +49,12 @@ def main():
     if "SQ_BUSY_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
         # SQ_* cycle counters are in quad-cycles summed over SEs/CUs as rocprofv3 reports them; ratios are unit-free
         derived["valu_busy_of_wave_cycles"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"] if avg.get("SQ_WAVE_CYCLES") else None
+    if "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
+        # SQ_ACTIVE_INST_VALU: quad-cycles during which a wave has a VALU instruction executing, summed over waves;
+        # a CDNA4 SIMD keeps two wave64 VALU instructions in flight (4 cycles each, 2-cycle issue), so 100 % busy is
+        # 2 x SIMDs x cycles.  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+        cycles = avg["GRBM_GUI_ACTIVE"] / 8.0
+        derived["valu_busy_frac"] = avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (2.0 * 1024.0 * cycles)
     if "SQ_INSTS_VALU" in avg and "SQ_WAVES" in avg:
         derived["valu_insts_per_wave"] = avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]
     if "FETCH_SIZE" in avg:
@@ -59,6 +65,9 @@ def main():
         derived["write_bytes"] = avg["WRITE_SIZE"] * 1024.0
     if "fetch_bytes_x2" in derived and "write_bytes" in derived:
         derived["hbm_bytes_per_launch"] = derived["fetch_bytes_x2"] + derived["write_bytes"]
+    if "hbm_bytes_per_launch" in derived and "kernel_s_profiled" in derived:
+        derived["hbm_gb_per_s"] = derived["hbm_bytes_per_launch"] / derived["kernel_s_profiled"] / 1e9
+        derived["hbm_frac_of_8tbs"] = derived["hbm_gb_per_s"] / 8000.0
     if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
         derived["l2_hit_rate"] = avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
     lines.append("")
