@@ -135,8 +135,8 @@ void resolve_config() {
   g.nslices = g.nranks > 1 ? g.nranks : (g.opt.jslices > 0 ? g.opt.jslices : 1);
   // AUTO: the hand-scheduled ISA loop (+6 % over hipcc's schedule of the same operations, profiles/r01_sweep_isa.txt)
   g.variant = g.opt.variant == NBODY_VARIANT_AUTO ? NBODY_VARIANT_ISA : g.opt.variant;
-  if (g.fp64) g.variant = NBODY_VARIANT_SMEM;
-  // the hand-scheduled loop exists for the timed arithmetic only; the study modes use the C++ kernels
+  if (g.fp64 && g.variant != NBODY_VARIANT_ISA) g.variant = NBODY_VARIANT_SMEM;   // fp64: ISA loop or the compiled SMEM kernel
+  // the hand-scheduled loops exist for the timed arithmetic only; the study modes use the C++ kernels
   if (g.variant == NBODY_VARIANT_ISA && (g.opt.arith != NBODY_ARITH_FMA3 || g.opt.sum_order != NBODY_SUM_SEQ)) g.variant = NBODY_VARIANT_SMEM;
   int R = g.opt.iblock;
   if (R == 0) R = (g.variant == NBODY_VARIANT_LDS || g.variant == NBODY_VARIANT_READLANE) ? 2 : 1;
@@ -283,6 +283,9 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, bo
   a.dt = dt; a.dt64 = dt64;
   const int R = g.R;
   dim3 grid(blocks_for(row_count, R), nsl * g.sub, 1);
+  if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
+    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f64<0>, grid, a) : launch_timed(L, force_isa_f64<1>, grid, a);
+  }
   if (g.fp64) {
     switch (R) {
       case 1: return launch_timed(L, force_smem_f64<1>, grid, a);

@@ -111,16 +111,18 @@ __device__ __forceinline__ void pair_f32(float xj, float yj, float zj, float xi,
   az = __builtin_fmaf(dz, inv3, az);
 }
 
-// fp64: v_rsq_f64 seed (about 2^-27 relative) + two Newton steps; same expression tree as
-// oracle/nbody_ref.c ref_forces_f64 apart from how 1/sqrt is obtained.
+// fp64: v_rsq_f64 seed (about 2^-27 relative) + two Newton steps y <- y + y*(1/2 - (x/2)*y*y), 7 operations;
+// same expression tree as oracle/nbody_ref.c ref_forces_f64 apart from how 1/sqrt is obtained, and the same
+// operations in the same order as the hand-scheduled fp64 loop (tools/gen_force_loop.py body_f64).
 __device__ __forceinline__ double rsqrt_f64(double x) {
   double y = __builtin_amdgcn_rsq(x);
-  double h = 0.5 * y;
-  double e = __builtin_fma(-x * y, y, 1.0);
-  y = __builtin_fma(h, e, y);
-  h = 0.5 * y;
-  e = __builtin_fma(-x * y, y, 1.0);
-  y = __builtin_fma(h, e, y);
+  double hx = x * 0.5;
+  double r = hx * y;
+  double e = __builtin_fma(-r, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  r = hx * y;
+  e = __builtin_fma(-r, y, 0.5);
+  y = __builtin_fma(y, e, y);
   return y;
 }
 __device__ __forceinline__ void pair_f64(double xj, double yj, double zj, double xi, double yi, double zi, double eps,
@@ -514,6 +516,64 @@ __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
       pn[i] = p;
     } else {
       d4 o = {ax[r], ay[r], az[r], 0.0};
+      ((d4*)a.partial)[(size_t)seg * a.n_rows + i] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fp64 with the hand-scheduled loop (force_loop_gfx950.inc, NB_FORCE_LOOP_F64_*): one body per lane, 4 sources
+// per iteration, every instruction 8 bytes (v_rsq_f64 in its _e64 encoding).  Same bits as force_smem_f64<1>.
+template <int PLACEMENT>
+__global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
+  int seg, jb, je;
+  block_segment(a, &seg, &jb, &je);
+  const double eps = (double)soft_f32();
+  const d4* rows = (const d4*)a.rows;
+  const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
+  const int row_end = a.row0 + a.row_count;
+  const d4 me = rows[i < row_end ? i : row_end - 1];
+  const double xi = me.x, yi = me.y, zi = me.z;
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  int j = jb;
+  const int groups = (je - jb) / NB_FORCE_LOOP_F64_GROUP;
+  if (groups > 0) {
+    const uint64_t p = (uint64_t)(uintptr_t)a.src + (uint64_t)jb * sizeof(d4);
+    if constexpr (PLACEMENT == 1) {
+      asm volatile(NB_FORCE_LOOP_F64_V1
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_F64_CLOBBERS);
+    } else {
+      asm volatile(NB_FORCE_LOOP_F64_V0
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_F64_CLOBBERS);
+    }
+    j += groups * NB_FORCE_LOOP_F64_GROUP;
+  }
+  const NB_CONST d4* src = (const NB_CONST d4*)(uintptr_t)a.src;
+  for (; j < je; ++j) {
+    d4 q = src[j];
+    pair_f64(q.x, q.y, q.z, xi, yi, zi, eps, ax, ay, az);
+  }
+  if (i < row_end) {
+    if (a.fused) {
+      d4* vel = (d4*)a.vel;
+      d4* pn = (d4*)a.pos_next_rows;
+      d4 v = vel[i];
+      v.x = __builtin_fma(a.dt64, ax, v.x);
+      v.y = __builtin_fma(a.dt64, ay, v.y);
+      v.z = __builtin_fma(a.dt64, az, v.z);
+      vel[i] = v;
+      d4 q;
+      q.x = __builtin_fma(v.x, a.dt64, xi);
+      q.y = __builtin_fma(v.y, a.dt64, yi);
+      q.z = __builtin_fma(v.z, a.dt64, zi);
+      q.w = me.w;
+      pn[i] = q;
+    } else {
+      d4 o = {ax, ay, az, 0.0};
       ((d4*)a.partial)[(size_t)seg * a.n_rows + i] = o;
     }
   }

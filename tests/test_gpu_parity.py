@@ -353,6 +353,62 @@ def test_coincident_bodies_stay_finite(nb, engine_factory):
     assert np.array_equal(bits(f[0]), bits(f[1]))
 
 
+def test_extreme_values_strict_bit_exact(nb, oracle_fast, engine_factory):
+    """Edge cases of the arithmetic, strict mode bit for bit against the oracle (NaN compared as NaN):
+    separations that underflow (d2 == eps), coordinates whose squares overflow (d2 = inf, inv = 0), huge and tiny
+    magnitudes mixed, exact duplicates, signed zeros."""
+    n = 600
+    pos, _ = nb.make_bodies(n, seed=77)
+    pos[10, :3] = pos[11, :3] + np.float32(1e-30)          # dx*dx underflows: d2 == eps exactly
+    pos[20, :3] = [3e19, -2e19, 1e19]                      # squares overflow to inf against everything else
+    pos[21, :3] = [1e-38, -1e-38, 0.0]                     # near the subnormal range
+    pos[22, :3] = [-0.0, 0.0, -0.0]
+    pos[23, :3] = [0.0, -0.0, 0.0]
+    pos[30:34, :3] = pos[29, :3]                           # five coincident bodies
+    pos[40, :3] = [1e10, 1e10, 1e10]
+    eng = engine_factory(n)
+    for arith, d2 in ((nb.ARITH_STRICT, O.D2_FMA3), (nb.ARITH_REFERENCE_STRICT, O.D2_REFERENCE)):
+        eng.set_option(nb.OPT_ARITH, arith)
+        eng.set_option(nb.OPT_JSUB, 1)
+        with np.errstate(all="ignore"):
+            want = oracle_fast.forces_f32(pos, d2=d2, rsqrt=O.RSQRT_F64)
+        got = eng.forces(pos)
+        nan_w, nan_g = np.isnan(want), np.isnan(got)
+        assert np.array_equal(nan_w, nan_g)
+        assert np.array_equal(bits(got)[~nan_g], bits(want)[~nan_w])
+    # the timed mode stays finite wherever the oracle is finite
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
+    got = eng.forces(pos)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+
+
+def test_nan_input_propagates(nb, engine_factory):
+    """A NaN coordinate poisons every force (all pairs see it), as in the RTL where NaN flows through the IP cores
+    (T/tb_sqrt.vhd:536-537: recip_sqrt(NaN) = NaN)."""
+    n = 300
+    pos, _ = nb.make_bodies(n, seed=5)
+    pos[7, 1] = np.nan
+    eng = engine_factory(n)
+    f = eng.forces(pos)
+    assert np.isnan(f[:, :3]).all() and np.all(f[:, 3] == 0)
+
+
+def test_mailbox_maximum_points(nb, oracle_fast, engine_factory):
+    """NUM_PTS is a 15-bit field and the RAM holds 32768 words (S/top_level.vhd:45, 185): N = 32767 is the largest
+    request the reference accepts; same image in, same layout out."""
+    n = nb.mailbox.MAX_POINTS
+    pos, _ = nb.make_bodies(n, seed=12)
+    ram_a = nb.mailbox.encode_request(pos)
+    eng = engine_factory(n)
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    eng.set_option(nb.OPT_JSUB, 1)
+    ram_b = nb.mailbox.run(eng, ram_a)
+    assert ram_b.shape == (n, 4) and nb.mailbox.decode_control(ram_a)["begin"] == 0
+    rows = np.r_[0:64, n // 2:n // 2 + 64, n - 64:n]
+    want = oracle_fast.forces_f32(pos[rows], pos)
+    assert np.array_equal(bits(ram_b[rows]), bits(want))
+
+
 def test_mailbox_front_end(nb, oracle_fast, engine_factory):
     """The reference's RAM images verbatim."""
     n = 1000
@@ -396,6 +452,31 @@ def test_fp64_path(nb, oracle_fast, engine_factory):
     oracle_fast.bodyForce(o2, ov2, 0.01)
     oracle_fast.integrate(o2, ov2, 0.01)
     assert np.abs(p2 - o2).max() < 1e-12 * np.abs(o2).max()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 9, 250, 1031])
+def test_fp64_isa_loop_equals_compiled_kernel(nb, oracle_fast, engine_factory, n):
+    """fp64 default (hand-scheduled loop, 4 sources per iteration + scalar tail) vs the hipcc-scheduled kernel: same bits;
+    and both within fp64 tolerance of the oracle."""
+    pos, vel = nb.make_bodies(n, seed=200 + n, dtype=np.float64)
+    eng = engine_factory(n, fp64=True)
+    eng.set_option(nb.OPT_JSUB, 1)
+    assert eng.config["variant"] == "isa"
+    a = eng.forces(pos)
+    eng.upload(pos, vel)
+    eng.step(0.01, 3)
+    pa, va = eng.download()
+    eng.set_option(nb.OPT_VARIANT, nb.VARIANT_SMEM)
+    eng.set_option(nb.OPT_IBLOCK, 1)
+    assert eng.config["variant"] == "smem"
+    assert np.array_equal(bits(a), bits(eng.forces(pos)))
+    eng.upload(pos, vel)
+    eng.step(0.01, 3)
+    pb, vb = eng.download()
+    assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(va), bits(vb))
+    want = oracle_fast.forces_f64(pos)
+    scale = max(np.abs(want[:, :3]).max(), 1e-300)
+    assert np.abs(a[:, :3] - want[:, :3]).max() / scale < 1e-13 or n == 1
 
 
 def test_virtual_multi_gpu_schedule_bitwise(nb, oracle_fast, engine_factory, monkeypatch):

@@ -102,6 +102,83 @@ def build(pad):
     return ins
 
 
+# ---- fp64 (BASELINE config 5's arithmetic): same structure, 19 instructions per pair, all VOP3 (8 bytes) once
+# v_rsq_f64 is written in its 64-bit encoding; 4 sources per iteration (two buffers of 2 bodies x 32 bytes).
+# 1/sqrt = v_rsq_f64 seed + two Newton steps in the 7-operation form of rsqrt_f64() in nbody_kernels.hpp
+#   hx = x/2;  r = hx*y; e = fma(-r, y, 1/2); y = fma(y, e, y)   (twice)
+D_T, D_HX, D_R, D_E, D_U = 32, 38, 40, 42, 44
+D_Y = [34, 36]
+D_DSETS = [(20, 22, 24), (26, 28, 30)]
+D_XI, D_YI, D_ZI, D_AX, D_AY, D_AZ, D_EPS = 8, 10, 12, 14, 16, 18, 34   # eps in s[34:35]
+GROUP_F64 = 4
+
+
+def vp(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def sp(r):
+    return "s[%d:%d]" % (r, r + 1)
+
+
+def body_f64(k, sbase, b):
+    y, yp = D_Y[k & 1], D_Y[(k - 1) & 1]
+    dx, dy, dz = D_DSETS[k & 1]
+    px, py, pz = D_DSETS[(k - 1) & 1]
+    s0 = sbase + 8 * b
+    out = [
+        "v_add_f64 %s, %s, -%s" % (vp(dx), sp(s0), vp(D_XI)),
+        "v_add_f64 %s, %s, -%s" % (vp(dy), sp(s0 + 2), vp(D_YI)),
+        "v_add_f64 %s, %s, -%s" % (vp(dz), sp(s0 + 4), vp(D_ZI)),
+        "v_fma_f64 %s, %s, %s, %s" % (vp(D_T), vp(dz), vp(dz), sp(D_EPS)),
+        "v_fma_f64 %s, %s, %s, %s" % (vp(D_T), vp(dy), vp(dy), vp(D_T)),
+        "v_fma_f64 %s, %s, %s, %s" % (vp(D_T), vp(dx), vp(dx), vp(D_T)),
+        "v_rsq_f64_e64 %s, %s" % (vp(y), vp(D_T)),
+        "v_fma_f64 %s, %s, %s, %s" % (vp(D_AX), vp(px), vp(yp), vp(D_AX)),
+        "v_fma_f64 %s, %s, %s, %s" % (vp(D_AY), vp(py), vp(yp), vp(D_AY)),
+        "v_fma_f64 %s, %s, %s, %s" % (vp(D_AZ), vp(pz), vp(yp), vp(D_AZ)),
+        "v_mul_f64 %s, %s, 0.5" % (vp(D_HX), vp(D_T)),
+    ]
+    for _ in range(2):
+        out += ["v_mul_f64 %s, %s, %s" % (vp(D_R), vp(D_HX), vp(y)),
+                "v_fma_f64 %s, -%s, %s, 0.5" % (vp(D_E), vp(D_R), vp(y)),
+                "v_fma_f64 %s, %s, %s, %s" % (vp(y), vp(y), vp(D_E), vp(y))]
+    out += ["v_mul_f64 %s, %s, %s" % (vp(D_U), vp(y), vp(y)), "v_mul_f64 %s, %s, %s" % (vp(y), vp(y), vp(D_U))]
+    return out
+
+
+def build_f64(pad):
+    px, py, pz = D_DSETS[1]
+    ins = [
+        "v_mov_b64 %s, %%[xi]" % vp(D_XI), "v_mov_b64 %s, %%[yi]" % vp(D_YI), "v_mov_b64 %s, %%[zi]" % vp(D_ZI),
+        "v_mov_b64 %s, %%[ax]" % vp(D_AX), "v_mov_b64 %s, %%[ay]" % vp(D_AY), "v_mov_b64 %s, %%[az]" % vp(D_AZ),
+        "s_mov_b64 %s, %%[eps]" % sp(D_EPS),
+        "s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1),
+        "s_mov_b32 s%d, %%[groups]" % CNT,
+        "s_movk_i32 s%d, 0x80" % STRIDE,
+        "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1),
+    ]
+    ins += ["v_mov_b64 %s, 0" % vp(r) for r in (px, py, pz, D_Y[1])]
+    ins.append(".p2align 6")
+    ins += ["s_nop 0"] * pad
+    ins.append("1:")
+    ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+    for b in range(2):
+        ins += body_f64(b, A_BASE, b)
+    ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+    ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    for b in range(2):
+        ins += body_f64(2 + b, B_BASE, b)
+    ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b"]
+    ins += ["v_fma_f64 %s, %s, %s, %s" % (vp(D_AX), vp(px), vp(D_Y[1]), vp(D_AX)),
+            "v_fma_f64 %s, %s, %s, %s" % (vp(D_AY), vp(py), vp(D_Y[1]), vp(D_AY)),
+            "v_fma_f64 %s, %s, %s, %s" % (vp(D_AZ), vp(pz), vp(D_Y[1]), vp(D_AZ))]
+    ins += ["s_waitcnt lgkmcnt(0)", "v_mov_b64 %%[ax], %s" % vp(D_AX), "v_mov_b64 %%[ay], %s" % vp(D_AY), "v_mov_b64 %%[az], %s" % vp(D_AZ)]
+    return ins
+
+
 def check(ins):
     """the hardware rules the loop is built on"""
     loop = ins[ins.index("1:"):]
@@ -134,6 +211,11 @@ def main():
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
         f.write("#define NB_FORCE_LOOP_GROUP %d\n" % GROUP)
+        for v, pad in ((0, 14), (1, 15)):
+            f.write("#define NB_FORCE_LOOP_F64_V%d \"%s\"\n" % (v, "\\n\\t".join(build_f64(pad))))
+        clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, STRIDE + 1)] + ["scc", "memory"]
+        f.write("#define NB_FORCE_LOOP_F64_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob64))
+        f.write("#define NB_FORCE_LOOP_F64_GROUP %d\n" % GROUP_F64)
     n_valu = len([i for i in build(15) if i.startswith("v_")])
     print("wrote %s (%d VALU instructions per iteration of %d bodies + prologue/drain)" % (OUT, n_valu, GROUP))
 
