@@ -147,14 +147,15 @@ void resolve_config() {
   int sub = g.opt.jsub;
   if (sub == 0) {
     const int cus = g.cu_count > 0 ? g.cu_count : 256;
-    // one GPU: 64 workgroups per CU in the launch; several GPUs: the launch over the rank's OWN slice alone
-    // (which runs while the other slices travel) already has 16 per CU
-    const int target_blocks = (g.nslices > 1 ? 16 : 64) * cus;
+    // one GPU: 128 workgroups per CU in the launch (N = 65536: 64 segments 4547 G/s, 32: 4466, 16: 4310, 8: 3981;
+    // N = 1M: 8 segments 4688, 4: 4660 — profiles/r01_sweep_isa.txt); several GPUs: the launch over the rank's OWN
+    // slice alone (which runs while the other slices travel) already has 16 per CU
+    const int target_blocks = (g.nslices > 1 ? 16 : 128) * cus;
     int b = blocks_for(n_local, R);
     sub = (target_blocks + b - 1) / b;
     int slice_len = g.n / g.nslices;
-    int max_sub = std::max(1, slice_len / 2048);   // keep >= 2048 sources per segment
-    sub = std::max(1, std::min(std::min(sub, 32), max_sub));
+    int max_sub = std::max(1, slice_len / 1024);   // keep >= 1024 sources per segment
+    sub = std::max(1, std::min(std::min(sub, 64), max_sub));
   }
   g.sub = sub;
   g.nseg = g.nslices * g.sub;
