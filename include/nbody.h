@@ -56,6 +56,7 @@ enum {
   NBODY_OPT_TIMING = 7,    /* 1: HIP events around every force kernel (nbody_kernel_time) */
   NBODY_OPT_COMM = 8,      /* NBODY_COMM_* (multi-GPU) */
   NBODY_OPT_OVERLAP = 9,   /* multi-GPU: 1 = start on the rank's own slice while the others travel (default), 0 = gather first */
+  NBODY_OPT_GRAPH = 12,    /* 1 (default): nbody_step on one GPU replays a HIP graph of two steps; 0: launch every kernel */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
   NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: 1 = the product loop (default), 0 = the same instructions placed one 4-byte
                               phase off — 27 % slower, kept so that the code-placement effect can be re-measured */

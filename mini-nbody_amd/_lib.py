@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libnbody_hip.so")
 
 # mirrors of the enums in include/nbody.h
-OPT_VARIANT, OPT_IBLOCK, OPT_JSUB, OPT_JSLICES, OPT_ARITH, OPT_SUM_ORDER, OPT_TIMING, OPT_COMM, OPT_OVERLAP, OPT_ISA_PHASE, OPT_WAVES_PER_SIMD = range(1, 12)
+OPT_VARIANT, OPT_IBLOCK, OPT_JSUB, OPT_JSLICES, OPT_ARITH, OPT_SUM_ORDER, OPT_TIMING, OPT_COMM, OPT_OVERLAP, OPT_ISA_PHASE, OPT_WAVES_PER_SIMD, OPT_GRAPH = range(1, 13)
 VARIANT_AUTO, VARIANT_SMEM, VARIANT_LDS, VARIANT_READLANE, VARIANT_ISA = range(5)
 ARITH_FMA3, ARITH_REFERENCE, ARITH_STRICT, ARITH_REFERENCE_STRICT = 0, 1, 2, 3
 SUM_SEQ, SUM_FPGA16 = 0, 1

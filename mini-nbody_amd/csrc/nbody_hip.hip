@@ -98,7 +98,7 @@ struct Local {
 
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
-  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0;
+  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1;
 };
 
 typedef int (*host_gather_fn)(void* user, void* host_words, int n_total, int word_bytes, int rank, int nranks);
@@ -107,6 +107,10 @@ struct Global {
   host_gather_fn host_gather = nullptr;   // multi-process fallback transport: slices exchanged through host memory
   void* host_gather_user = nullptr;
   void* host_stage = nullptr;             // pinned staging buffer, N words
+  // HIP graph of TWO consecutive steps (the position buffers swap every step, so a pair returns to the same state):
+  // replayed by nbody_step when one GPU runs many short steps (launch-bound regime)
+  hipGraphExec_t step_graph = nullptr;
+  float graph_dt = 0.f; double graph_dt64 = 0.0; int graph_cur = -1;
   bool init = false;
   int n = 0, fp64 = 0, tile = 256;
   int nranks = 1, nlocal = 0;
@@ -154,7 +158,7 @@ void resolve_config() {
     int b = blocks_for(n_local, R);
     sub = (target_blocks + b - 1) / b;
     int slice_len = g.n / g.nslices;
-    int max_sub = std::max(1, slice_len / 1024);   // keep >= 1024 sources per segment
+    int max_sub = std::max(1, slice_len / 256);    // keep >= 256 sources per segment (a wave walks its segment serially)
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
   }
   g.sub = sub;
@@ -188,8 +192,15 @@ int ensure_partial(Local& L) {
   return NBODY_OK;
 }
 
+void drop_step_graph() {
+  if (g.step_graph) { (void)hipGraphExecDestroy(g.step_graph); g.step_graph = nullptr; }
+  g.graph_cur = -1;
+}
+
 int reconfigure() {
+  const int o_variant = g.variant, o_R = g.R, o_sub = g.sub, o_nsl = g.nslices;
   resolve_config();
+  if (o_variant != g.variant || o_R != g.R || o_sub != g.sub || o_nsl != g.nslices) drop_step_graph();
   size_t maxneed = 0;
   for (int l = 0; l < g.nlocal; ++l) {
     NBC(ensure_partial(g.loc[l]));
@@ -598,7 +609,31 @@ int step_impl(float dt, double dt64, int nsteps) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (nsteps < 0) return NBODY_ERR_ARG;
   NBC(reconfigure());
-  for (int s = 0; s < nsteps; ++s) NBC(enqueue_step(dt, dt64));
+  int s = 0;
+  // One GPU, no per-kernel timing events, enough steps: replay a captured pair of steps.  A step is 1-2 kernel
+  // launches + an event; below N ~ 10^5 the host launch path, not the GPU, sets the pace.
+  if (g.opt.graph && g.nranks == 1 && g.nlocal == 1 && !g.opt.timing && nsteps >= 4) {
+    Local& L = g.loc[0];
+    HIPC(hipSetDevice(L.device));
+    if (!g.step_graph || g.graph_cur != L.cur || g.graph_dt != dt || g.graph_dt64 != dt64) {
+      drop_step_graph();
+      hipGraph_t graph = nullptr;
+      const long long done = g.steps_done;
+      HIPC(hipStreamBeginCapture(L.compute, hipStreamCaptureModeThreadLocal));
+      int rc = enqueue_step(dt, dt64);
+      if (!rc) rc = enqueue_step(dt, dt64);
+      hipError_t e = hipStreamEndCapture(L.compute, &graph);
+      g.steps_done = done;                       // capturing executes nothing
+      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      HIPC(e);
+      e = hipGraphInstantiate(&g.step_graph, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      HIPC(e);
+      g.graph_cur = L.cur; g.graph_dt = dt; g.graph_dt64 = dt64;
+    }
+    for (; s + 2 <= nsteps; s += 2) { HIPC(hipGraphLaunch(g.step_graph, L.compute)); g.steps_done += 2; }
+  }
+  for (; s < nsteps; ++s) NBC(enqueue_step(dt, dt64));
   return NBODY_OK;
 }
 
@@ -772,10 +807,20 @@ int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void*
   g.opt = Options();
   e = reconfigure();
   if (e) { nbody_shutdown(); return e; }
+  if (nranks > 1 && L.comm_h) {
+    // One all-gather of the (zeroed) position buffer now: RCCL sets up its rings/channels lazily on the first
+    // collective, and that must not land in a caller's first timed step.
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipEventRecord(L.ev_own_ready, L.compute));
+    e = enqueue_gather(L.cur);
+    if (!e) e = sync_all();
+    if (e) { nbody_shutdown(); return e; }
+  }
   return NBODY_OK;
 }
 
 void nbody_shutdown(void) {
+  drop_step_graph();
   for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);
   if (g.host_stage) { (void)hipHostFree(g.host_stage); g.host_stage = nullptr; }
   g.host_gather = nullptr; g.host_gather_user = nullptr;
@@ -793,11 +838,12 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
     case NBODY_OPT_COMM: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: g.opt.overlap = value ? 1 : 0; break;
+    case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
     case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
     default: return NBODY_ERR_ARG;
   }
-  if (g.init) { NBC(sync_all()); return reconfigure(); }
+  if (g.init) { NBC(sync_all()); drop_step_graph(); return reconfigure(); }
   return NBODY_OK;
 }
 

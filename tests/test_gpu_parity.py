@@ -508,3 +508,59 @@ def test_virtual_multi_gpu_schedule_bitwise(nb, oracle_fast, engine_factory, mon
             gp, gv = results[(P, overlap)]
             assert np.array_equal(bits(gp), bits(wp)), (P, overlap)
             assert np.array_equal(bits(gv), bits(wv)), (P, overlap)
+
+
+@pytest.mark.parametrize("fp64", [False, True])
+def test_virtual_eight_ranks_all_entry_points(nb, engine_factory, monkeypatch, fp64):
+    """P = 8 virtual ranks (the driver's 8-GPU shape) on a ragged N: device loop, host-pointer bodyForce()/integrate()
+    and the force-only entry point all equal the one-GPU run with the same segmentation, bit for bit."""
+    monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
+    n, P, dt = 4099, 8, 0.01
+    dtype = np.float64 if fp64 else np.float32
+    pos, vel = nb.make_bodies(n, seed=61, dtype=dtype)
+
+    def run(eng):
+        eng.set_option(nb.OPT_JSUB, 2)
+        out = {}
+        out["forces"] = eng.forces(pos)
+        p, v = pos.copy(), vel.copy()
+        for _ in range(2):
+            eng.bodyForce(p, v, dt)
+            eng.integrate(p, v, dt)
+        out["host_loop"] = (p, v)
+        eng.upload(pos, vel)
+        eng.step(dt, 3)
+        out["device_loop"] = eng.download()
+        return out
+
+    multi = run(engine_factory(n, ngpus=P, fp64=fp64))
+    one_eng = engine_factory(n, fp64=fp64)
+    one_eng.set_option(nb.OPT_JSLICES, P)
+    one = run(one_eng)
+    assert np.array_equal(bits(multi["forces"]), bits(one["forces"]))
+    for key in ("host_loop", "device_loop"):
+        for a, b in zip(multi[key], one[key]):
+            assert np.array_equal(bits(a), bits(b)), key
+
+
+def test_step_graph_replay_equals_eager(nb, engine_factory):
+    """nbody_step on one GPU replays a HIP graph of two steps (launch-bound regime); results must not depend on it,
+    for even and odd step counts, after an upload in between, and after an option change."""
+    n = 3000
+    pos, vel = nb.make_bodies(n, seed=8)
+    eng = engine_factory(n)
+    out = {}
+    for graph in (1, 0):
+        eng.set_option(nb.OPT_GRAPH, graph)
+        eng.upload(pos, vel)
+        eng.step(0.01, 7)
+        a = eng.download()
+        eng.step(0.01, 4)
+        eng.set_option(nb.OPT_JSUB, 3)
+        eng.step(0.005, 6)
+        b = eng.download()
+        eng.set_option(nb.OPT_JSUB, 0)
+        out[graph] = (a, b)
+    for k in (0, 1):
+        for x, y in zip(out[1][k], out[0][k]):
+            assert np.array_equal(bits(x), bits(y))
