@@ -87,7 +87,6 @@ struct Local {
   bool all_present = true;             // pos[cur] holds every slice
   hipEvent_t ev_own_ready = nullptr;   // the rank's slice of pos[cur] is written
   hipEvent_t ev_gather[kMaxRanks] = {};
-  hipEvent_t ev_compute_done = nullptr;
   ncclComm_t comm_h = nullptr;
   // force-kernel timing
   hipEvent_t t0[kTimerRing] = {}, t1[kTimerRing] = {};
@@ -177,7 +176,6 @@ int alloc_local(Local& L) {
   HIPC(hipMemset(L.vel, 0, (L.n_local + pad) * wb));
   HIPC(hipMemset(L.force, 0, (L.n_local + pad) * wb));
   HIPC(hipEventCreateWithFlags(&L.ev_own_ready, hipEventDisableTiming));
-  HIPC(hipEventCreateWithFlags(&L.ev_compute_done, hipEventDisableTiming));
   for (int s = 0; s < g.nranks && s < kMaxRanks; ++s) HIPC(hipEventCreateWithFlags(&L.ev_gather[s], hipEventDisableTiming));
   for (int k = 0; k < kTimerRing; ++k) { HIPC(hipEventCreate(&L.t0[k])); HIPC(hipEventCreate(&L.t1[k])); }
   return NBODY_OK;
@@ -450,10 +448,8 @@ int enqueue_step(float dt, double dt64) {
   }
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
-    if (P > 1) {
-      // the comm stream must not start the NEXT gather into a buffer this step still reads: it waits
-      // on ev_own_ready (recorded after this step's last kernel) inside enqueue_gather.
-    }
+    // (the NEXT gather writes into the buffer this step read; it waits on ev_own_ready, recorded after this
+    //  step's last kernel, inside enqueue_gather)
     L.cur ^= 1;
     L.all_present = (P == 1);
   }
@@ -519,7 +515,6 @@ void free_local(Local& L) {
   if (L.force) (void)hipFree(L.force);
   if (L.vel_full) (void)hipFree(L.vel_full);
   if (L.ev_own_ready) (void)hipEventDestroy(L.ev_own_ready);
-  if (L.ev_compute_done) (void)hipEventDestroy(L.ev_compute_done);
   for (int s = 0; s < kMaxRanks; ++s) if (L.ev_gather[s]) (void)hipEventDestroy(L.ev_gather[s]);
   for (int k = 0; k < kTimerRing; ++k) { if (L.t0[k]) (void)hipEventDestroy(L.t0[k]); if (L.t1[k]) (void)hipEventDestroy(L.t1[k]); }
   if (L.compute) (void)hipStreamDestroy(L.compute);
@@ -701,6 +696,7 @@ int integrate_impl(void* pos, const void* vel, float dt, double dt64, int n) {
 int forces_impl(const void* pos_words, void* force_words, int n) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (n != g.n || !pos_words || !force_words) return NBODY_ERR_ARG;
+  if (g.multiprocess && g.nranks > 1) return NBODY_ERR_UNSUPPORTED;   // force words of other processes are not gathered
   const size_t wb = word_bytes();
   NBC(sync_all());
   for (int l = 0; l < g.nlocal; ++l) {
@@ -715,7 +711,6 @@ int forces_impl(const void* pos_words, void* force_words, int n) {
     HIPC(hipSetDevice(L.device));
     HIPC(hipMemcpy((char*)force_words + (size_t)L.first * wb, L.force, (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
   }
-  if (g.multiprocess && g.nranks > 1) return NBODY_ERR_UNSUPPORTED;  // force words of other ranks are not gathered
   return NBODY_OK;
 }
 
