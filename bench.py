@@ -91,6 +91,16 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     args = ap.parse_args()
 
+    if not os.path.exists(os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so")):
+        # fresh checkout (built files are git-ignored): build the HIP library; a failure is fatal, there is no fallback
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            subprocess.run(["make", "lib"], cwd=ROOT, check=True, capture_output=True)
+        else:
+            for _ in range(600):
+                if os.path.exists(os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so")):
+                    break
+                time.sleep(0.5)
+            time.sleep(2.0)
     import torch
     nb = importlib.import_module("mini-nbody_amd")
     from importlib import import_module

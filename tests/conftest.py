@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Built artefacts are git-ignored; on a fresh checkout build them once (hipcc cross-compiles without a GPU).
+    A failing build fails the session loudly: there is no fallback to test instead."""
+    import subprocess
+    need = [os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"),
+            os.path.join(ROOT, "oracle", "libnbody_ref.so"), os.path.join(ROOT, "oracle", "libnbody_ref_fast.so")]
+    if all(os.path.exists(p) for p in need):
+        return
+    r = subprocess.run(["make", "lib", "host", "oracle"], cwd=ROOT, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise pytest.UsageError("`make lib host oracle` failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """Serial, bit-reproducible oracle build (test infrastructure)."""
