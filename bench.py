@@ -156,8 +156,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
     cfg = eng.config
-    p1, _ = eng.download()
-    finite = bool(np.isfinite(p1).all())
+    # sanity of the state the timed steps produced: this rank's own slice, without any collective (nothing after the
+    # timed region may stall the report)
+    p_own, _ = eng.download_slice()
+    finite = bool(np.isfinite(p_own).all())
 
     if rank == 0:
         pairs_per_step = float(n) * float(n)

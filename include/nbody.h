@@ -105,6 +105,9 @@ const char *nbody_error_string(int code);
  * Arrays are always the FULL N bodies, on every rank; a rank keeps its own slice of vel. */
 int nbody_upload(const BodySystem *host);
 int nbody_download(BodySystem *host);
+/* This rank's own bodies only: n_local words of pos and of vel (float or double words as the context was created),
+ * no collective.  With one GPU it is the whole system. */
+int nbody_download_slice(void *pos_words, void *vel_words);
 int nbody_upload_d(const BodySystemD *host);
 int nbody_download_d(BodySystemD *host);
 

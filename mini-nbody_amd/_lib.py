@@ -26,7 +26,7 @@ SYMBOLS = [
     "nbody_error_string", "nbody_upload", "nbody_download", "nbody_upload_d", "nbody_download_d", "bodyForce",
     "integrate", "bodyForce_d", "integrate_d", "nbody_step", "nbody_step_d", "nbody_sync", "nbody_forces",
     "nbody_forces_d", "nbody_forces_rows", "nbody_mailbox_run", "nbody_kernel_time", "nbody_device_ptr",
-    "nbody_set_host_gather",
+    "nbody_set_host_gather", "nbody_download_slice",
 ]
 
 
@@ -69,7 +69,7 @@ def load():
         "nbody_forces": [fp, fp, i], "nbody_forces_d": [dp, dp, i], "nbody_forces_rows": [i, i, fp],
         "nbody_mailbox_run": [vp, vp, i], "nbody_kernel_time": [C.POINTER(d), C.POINTER(C.c_longlong), i],
         "nbody_device_ptr": [i, C.POINTER(vp), C.POINTER(C.c_size_t)],
-        "nbody_set_host_gather": [HOST_GATHER_FN, vp],
+        "nbody_set_host_gather": [HOST_GATHER_FN, vp], "nbody_download_slice": [vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

@@ -360,6 +360,33 @@ int host_exchange(Local& L, void* dev_full, int first, int count, bool wait_own_
   return NBODY_OK;
 }
 
+// RCCL all-gather of one sharded device array in place on the comm stream (multi-process): one ncclAllGather when the
+// slices are equal (default), else / on request P-1 ring steps of ncclSend + ncclRecv.  ev[s] (s = 1..P-1), if given,
+// is recorded when ring step s has landed (all of them after the collective in the ncclAllGather form).
+int rccl_gather(Local& L, void* dev_full, hipEvent_t* ev) {
+  const int P = g.nranks;
+  const size_t wb = word_bytes();
+  const bool even = (g.n % P) == 0;
+  if (even && (g.opt.comm == NBODY_COMM_ALLGATHER || g.opt.comm == NBODY_COMM_AUTO)) {
+    NCCLC(g_rccl.AllGather(word_ptr(dev_full, L.first), dev_full, (size_t)L.n_local * wb, ncclChar, L.comm_h, L.comm));
+    if (ev) for (int s = 1; s < P; ++s) HIPC(hipEventRecord(ev[s], L.comm));
+    return NBODY_OK;
+  }
+  const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
+  for (int s = 1; s < P; ++s) {
+    const int qs = ring_slice(L.rank, s - 1);   // forward what arrived last (own slice at s = 1)
+    const int qr = ring_slice(L.rank, s);
+    const int fs = slice_first(qs, g.n, P), ls = slice_first(qs + 1, g.n, P) - fs;
+    const int fr = slice_first(qr, g.n, P), lr = slice_first(qr + 1, g.n, P) - fr;
+    NCCLC(g_rccl.GroupStart());
+    NCCLC(g_rccl.Send(word_ptr(dev_full, fs), (size_t)ls * wb, ncclChar, next, L.comm_h, L.comm));
+    NCCLC(g_rccl.Recv(word_ptr(dev_full, fr), (size_t)lr * wb, ncclChar, prev, L.comm_h, L.comm));
+    NCCLC(g_rccl.GroupEnd());
+    if (ev) HIPC(hipEventRecord(ev[s], L.comm));
+  }
+  return NBODY_OK;
+}
+
 // Bring the other ranks' slices of pos[buf] to every local.  Enqueued on the comm streams; records
 // ev_gather[s] (s = 1..P-1) as slices arrive.  Sources are valid after their owner's ev_own_ready.
 int enqueue_gather(int buf) {
@@ -392,25 +419,7 @@ int enqueue_gather(int buf) {
     return NBODY_OK;
   }
   HIPC(hipStreamWaitEvent(L.comm, L.ev_own_ready, 0));
-  const bool even = (g.n % P) == 0;
-  if (even && (g.opt.comm == NBODY_COMM_ALLGATHER || g.opt.comm == NBODY_COMM_AUTO)) {
-    NCCLC(g_rccl.AllGather(word_ptr(L.pos[buf], L.first), L.pos[buf], (size_t)L.n_local * wb, ncclChar, L.comm_h, L.comm));
-    for (int s = 1; s < P; ++s) HIPC(hipEventRecord(L.ev_gather[s], L.comm));
-    return NBODY_OK;
-  }
-  const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
-  for (int s = 1; s < P; ++s) {
-    const int qs = ring_slice(L.rank, s - 1);   // forward what arrived last (own slice at s = 1)
-    const int qr = ring_slice(L.rank, s);
-    const int fs = slice_first(qs, g.n, P), ls = slice_first(qs + 1, g.n, P) - fs;
-    const int fr = slice_first(qr, g.n, P), lr = slice_first(qr + 1, g.n, P) - fr;
-    NCCLC(g_rccl.GroupStart());
-    NCCLC(g_rccl.Send(word_ptr(L.pos[buf], fs), (size_t)ls * wb, ncclChar, next, L.comm_h, L.comm));
-    NCCLC(g_rccl.Recv(word_ptr(L.pos[buf], fr), (size_t)lr * wb, ncclChar, prev, L.comm_h, L.comm));
-    NCCLC(g_rccl.GroupEnd());
-    HIPC(hipEventRecord(L.ev_gather[s], L.comm));
-  }
-  return NBODY_OK;
+  return rccl_gather(L, L.pos[buf], L.ev_gather);
 }
 
 // One step on every local: forces on pos[cur], kick, drift into pos[cur^1], swap.
@@ -539,7 +548,6 @@ int upload_impl(const void* pos, const void* vel) {
 }
 
 int gather_vel_multiprocess(Local& L) {
-  const int P = g.nranks;
   const size_t wb = word_bytes();
   HIPC(hipSetDevice(L.device));
   if (!L.vel_full) HIPC(hipMalloc(&L.vel_full, (size_t)(g.n + 64) * wb));
@@ -550,16 +558,7 @@ int gather_vel_multiprocess(Local& L) {
     HIPC(hipStreamSynchronize(L.comm));
     return NBODY_OK;
   }
-  const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
-  for (int s = 1; s < P; ++s) {
-    const int qs = ring_slice(L.rank, s - 1), qr = ring_slice(L.rank, s);
-    const int fs = slice_first(qs, g.n, P), ls = slice_first(qs + 1, g.n, P) - fs;
-    const int fr = slice_first(qr, g.n, P), lr = slice_first(qr + 1, g.n, P) - fr;
-    NCCLC(g_rccl.GroupStart());
-    NCCLC(g_rccl.Send(word_ptr(L.vel_full, fs), (size_t)ls * wb, ncclChar, next, L.comm_h, L.comm));
-    NCCLC(g_rccl.Recv(word_ptr(L.vel_full, fr), (size_t)lr * wb, ncclChar, prev, L.comm_h, L.comm));
-    NCCLC(g_rccl.GroupEnd());
-  }
+  NBC(rccl_gather(L, L.vel_full, nullptr));
   HIPC(hipStreamSynchronize(L.comm));
   return NBODY_OK;
 }
@@ -883,6 +882,19 @@ const char* nbody_error_string(int code) {
   if (code >= 2000) { snprintf(buf, sizeof(buf), "RCCL error %d near nbody_hip.hip:%d", code - 2000, g_last_line); return buf; }
   snprintf(buf, sizeof(buf), "nbody: unknown error %d", code);
   return buf;
+}
+
+int nbody_download_slice(void* pos_words, void* vel_words) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!pos_words || !vel_words) return NBODY_ERR_ARG;
+  if (g.nlocal != 1) return NBODY_ERR_UNSUPPORTED;      // one process driving several devices owns every slice: nbody_download
+  NBC(sync_all());
+  Local& L = g.loc[0];
+  const size_t wb = word_bytes();
+  HIPC(hipSetDevice(L.device));
+  HIPC(hipMemcpy(pos_words, word_ptr(L.pos[L.cur], L.first), (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(vel_words, L.vel, (size_t)L.n_local * wb, hipMemcpyDeviceToHost));
+  return NBODY_OK;
 }
 
 int nbody_upload(const BodySystem* host) { if (!host) return NBODY_ERR_ARG; if (g.init && g.fp64) return NBODY_ERR_STATE; return upload_impl(host->pos, host->vel); }

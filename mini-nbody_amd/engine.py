@@ -68,6 +68,14 @@ class NBody:
         L.check((self.lib.nbody_download_d if self.fp64 else self.lib.nbody_download)(C.byref(bs)))
         return pos, vel
 
+    def download_slice(self):
+        """This rank's own bodies only (n_local words each), no collective."""
+        cnt = self.info(L.INFO_N_LOCAL)
+        pos = np.empty((cnt, 4), self.dtype)
+        vel = np.empty((cnt, 4), self.dtype)
+        L.check(self.lib.nbody_download_slice(pos.ctypes.data_as(C.c_void_p), vel.ctypes.data_as(C.c_void_p)))
+        return pos, vel
+
     # ---- the path: same names and argument meaning as the C entry points ----
     def bodyForce(self, pos, vel, dt):
         """v += dt * F(pos), in place on vel; pos is read-only."""
