@@ -28,11 +28,14 @@ microbench: build/microbench build/microbench_streams
 build/microbench: $(CSRC)/microbench.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+# 0.5 MB of generated instruction streams: produced on demand, not tracked
+$(CSRC)/microbench_streams.inc: tools/gen_streams.py tools/gen_force_loop.py
+	python3 tools/gen_streams.py
 build/microbench_streams: $(CSRC)/microbench_streams.hip $(CSRC)/microbench_streams.inc
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
-# generated sources (committed): the hand-scheduled loop and the microbenchmark streams
+# generated sources: the hand-scheduled loop (committed) and the microbenchmark streams (not tracked)
 gen:
 	python3 tools/gen_force_loop.py
 	python3 tools/gen_streams.py
