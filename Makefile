@@ -24,8 +24,11 @@ build/nbody: $(PKG)/host/nbody.c include/nbody.h include/nbody_ic.h $(PKG)/libnb
 oracle:
 	$(MAKE) -C oracle
 
-microbench: build/microbench build/microbench_streams
+microbench: build/microbench build/microbench_streams build/microbench_roles
 build/microbench: $(CSRC)/microbench.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+build/microbench_roles: $(CSRC)/microbench_roles.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 # 0.5 MB of generated instruction streams: produced on demand, not tracked
