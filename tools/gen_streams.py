@@ -493,6 +493,35 @@ for nm, pat in ORDERS.items():
                         sorted(set(vregs(body)), key=lambda r: int(r[1:])), pre))
 
 
+# ---- 3-stage software pipeline, single chain, good phase: slot k = S,F of body k | rsq of body k-1 | M,A of body k-2
+T3 = [20, 24, 26]
+D3 = [(21, 23, 25), (27, 29, 31), (33, 35, 37)]
+
+
+def ops3(k):
+    t, (dx, dy, dz) = T3[k % 3], D3[k % 3]
+    sx = 36 + 4 * (k % 8)
+    return dict(
+        S=["v_sub_f32_e64 v%d, s%d, v8" % (dx, sx), "v_sub_f32_e64 v%d, s%d, v9" % (dy, sx + 1), "v_sub_f32_e64 v%d, s%d, v10" % (dz, sx + 2)],
+        F=["v_fma_f32 v%d, v%d, v%d, s34" % (t, dz, dz), "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dy, dy, t), "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dx, dx, t)],
+        R=["v_rsq_f32_e64 v%d, v%d" % (t, t)],
+        M=["v_mul_f32_e64 v22, v%d, v%d" % (t, t), "v_mul_f32_e64 v%d, v%d, v22" % (t, t)],
+        A=["v_fma_f32 v12, v%d, v%d, v12" % (dx, t), "v_fma_f32 v13, v%d, v%d, v13" % (dy, t), "v_fma_f32 v14, v%d, v%d, v14" % (dz, t)])
+
+
+for nm, order in (("p3_SFRMA", "SFRMA"), ("p3_RSFMA", "RSFMA"), ("p3_SFMAR", "SFMAR"), ("p3_MASFR", "MASFR")):
+    body3 = []
+    for k in range(24):            # 24 bodies = lcm(3 register sets, 8 sources)
+        part = {"S": ops3(k)["S"], "F": ops3(k)["F"], "R": ops3(k - 1)["R"], "M": ops3(k - 2)["M"], "A": ops3(k - 2)["A"]}
+        for ch in order:
+            body3 += part[ch]
+    check_banks(body3)
+    for kk in (0, 1):
+        pre = [".p2align 6"] + ["s_nop 0"] * kk
+        streams.append(("%s_k%d" % (nm, kk), "3-stage pipeline, single chain, slot order %s" % order, body3, len(body3),
+                        sorted(set(vregs(body3)), key=lambda r: int(r[1:])), pre))
+
+
 def main():
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_streams.py — do not edit.\n")
