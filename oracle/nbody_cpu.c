@@ -1,0 +1,68 @@
+/* nbody_cpu.c — BASELINE config 1 ("N=4096 fp32, 10 iters, reference nbody.c on host CPU: plumbing, no GPU").
+ *
+ * TEST INFRASTRUCTURE / CPU BASELINE, not product code: the reference tree has no nbody.c, so this is
+ * the oracle (nbody_ref.c) behind the same command line, initial conditions, loop and report line as the GPU host
+ * program mini-nbody_amd/host/nbody.c — which makes the two directly comparable (same checksum in --strict mode).
+ *
+ * usage: nbody_cpu [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T]
+ */
+#define _POSIX_C_SOURCE 199309L
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "nbody_ref.h"
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char **argv) {
+  int n = 4096, iters = 10, fp64 = 0, npos = 0, rsq = REF_RSQRT_F64, threads = 0;
+  unsigned long long seed = 42ull;
+  for (int a = 1; a < argc; ++a) {
+    if (!strcmp(argv[a], "--fp64")) fp64 = 1;
+    else if (!strcmp(argv[a], "--divsqrt")) rsq = REF_RSQRT_DIVSQRT;
+    else if (!strcmp(argv[a], "--seed") && a + 1 < argc) seed = strtoull(argv[++a], NULL, 10);
+    else if (!strcmp(argv[a], "--threads") && a + 1 < argc) threads = atoi(argv[++a]);
+    else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
+    else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T]\n", argv[0]); return 2; }
+  }
+  if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
+  if (threads > 0) ref_set_num_threads(threads);
+  const float dt = 0.01f;
+  double total = 0.0, cx = 0, cy = 0, cz = 0;
+  if (!fp64) {
+    float *pos = (float *)malloc(sizeof(float) * 4 * (size_t)n), *vel = (float *)malloc(sizeof(float) * 4 * (size_t)n);
+    ref_ic_f32(pos, vel, n, 0, n, seed);
+    for (int it = 1; it <= iters; ++it) {
+      double t0 = now_s();
+      ref_bodyForce_f32(pos, vel, dt, n, REF_D2_FMA3, rsq, REF_SUM_SEQ);
+      ref_integrate_f32(pos, vel, dt, n);
+      if (it > 1) total += now_s() - t0;
+    }
+    for (int i = 0; i < n; ++i) { cx += pos[4 * i]; cy += pos[4 * i + 1]; cz += pos[4 * i + 2]; }
+    printf("checksum (sum of positions): %.9g %.9g %.9g\n", cx, cy, cz);
+    free(pos); free(vel);
+  } else {
+    double *pos = (double *)malloc(sizeof(double) * 4 * (size_t)n), *vel = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+    ref_ic_f64(pos, vel, n, 0, n, seed);
+    for (int it = 1; it <= iters; ++it) {
+      double t0 = now_s();
+      ref_bodyForce_f64(pos, vel, (double)dt, n);
+      ref_integrate_f64(pos, vel, (double)dt, n);
+      if (it > 1) total += now_s() - t0;
+    }
+    for (int i = 0; i < n; ++i) { cx += pos[4 * i]; cy += pos[4 * i + 1]; cz += pos[4 * i + 2]; }
+    printf("checksum (sum of positions): %.17g %.17g %.17g\n", cx, cy, cz);
+    free(pos); free(vel);
+  }
+  double avg = total / (double)(iters - 1);
+  printf("%d Bodies (%s, host CPU, %d threads): average %0.3f Billion Interactions / second (%.3f ms / step)\n", n,
+         fp64 ? "fp64" : "fp32", ref_num_threads(), 1e-9 * (double)n * (double)n / avg, 1e3 * avg);
+  return 0;
+}

@@ -21,7 +21,7 @@ _fp = C.POINTER(C.c_float)
 
 
 def build(force=False):
-    if force or not all(os.path.exists(os.path.join(HERE, f)) for f in ("libnbody_ref.so", "libnbody_ref_fast.so")):
+    if force or not all(os.path.exists(os.path.join(HERE, f)) for f in ("libnbody_ref.so", "libnbody_ref_fast.so", "nbody_cpu")):
         subprocess.run(["make", "-C", HERE] + (["-B"] if force else []), check=True, capture_output=True)
 
 

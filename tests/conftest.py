@@ -19,7 +19,8 @@ def pytest_sessionstart(session):
     A failing build fails the session loudly: there is no fallback to test instead."""
     import subprocess
     need = [os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"),
-            os.path.join(ROOT, "oracle", "libnbody_ref.so"), os.path.join(ROOT, "oracle", "libnbody_ref_fast.so")]
+            os.path.join(ROOT, "oracle", "libnbody_ref.so"), os.path.join(ROOT, "oracle", "libnbody_ref_fast.so"),
+            os.path.join(ROOT, "oracle", "nbody_cpu")]
     if all(os.path.exists(p) for p in need):
         return
     r = subprocess.run(["make", "lib", "host", "oracle"], cwd=ROOT, capture_output=True, text=True)

@@ -29,3 +29,15 @@ def test_c_host_program_matches_oracle(nb, oracle_fast, extra):
     want = pos[:, :3].astype(np.float64).sum(0)
     assert np.allclose(got, want, rtol=0, atol=1e-6 * np.abs(pos[:, :3]).sum()), (got, want)   # printed with %.9g
     assert re.search(r"%d Bodies .* Billion Interactions / second" % n, out.stdout)
+
+
+def test_gpu_host_program_and_cpu_program_print_the_same_checksum():
+    """BASELINE config 1 (CPU program, oracle/nbody_cpu) next to the GPU host program in --strict mode, one source
+    segment: identical initial conditions, identical arithmetic, identical checksum line."""
+    cpu = os.path.join(ROOT, "oracle", "nbody_cpu")
+    assert os.path.exists(cpu) and os.path.exists(EXE)
+    a = subprocess.run([cpu, "4096", "10"], capture_output=True, text=True, timeout=300)
+    b = subprocess.run([EXE, "4096", "10", "--strict", "--jsub", "1"], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    line = lambda out: [l for l in out.splitlines() if l.startswith("checksum")][0]
+    assert line(a.stdout) == line(b.stdout)

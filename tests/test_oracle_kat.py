@@ -107,3 +107,22 @@ def test_acc_in_continues_the_sum(oracle):
     part = oracle.forces_f32(pos, pos[:123])
     both = oracle.forces_f32(pos, pos[123:], acc_in=part)
     assert np.array_equal(full.view(np.uint32), both.view(np.uint32))
+
+
+def test_config1_cpu_program(oracle_fast):
+    """BASELINE config 1: N = 4096 fp32, 10 iterations on the host CPU, as a program (oracle/nbody_cpu.c).  Its checksum
+    equals the oracle library's; tests/test_gpu_c_host.py checks that the GPU host program prints the same in --strict."""
+    import re
+    import subprocess
+    import oracle as O
+    exe = os.path.join(os.path.dirname(O.__file__), "nbody_cpu")
+    assert os.path.exists(exe), "make -C oracle"
+    out = subprocess.run([exe, "4096", "10"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"checksum \(sum of positions\): (\S+) (\S+) (\S+)", out.stdout)
+    got = np.array([float(m.group(k)) for k in (1, 2, 3)])
+    pos, vel = oracle_fast.ic(4096)
+    oracle_fast.step(pos, vel, 0.01, 10)
+    want = pos[:, :3].astype(np.float64).sum(0)
+    assert np.allclose(got, want, rtol=0, atol=1e-6 * np.abs(pos[:, :3]).sum())
+    assert re.search(r"4096 Bodies \(fp32, host CPU, \d+ threads\): average \S+ Billion Interactions / second", out.stdout)
