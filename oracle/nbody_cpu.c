@@ -33,7 +33,11 @@ int main(int argc, char **argv) {
     else { fprintf(stderr, "usage: %s [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
-  if (threads > 0) ref_set_num_threads(threads);
+  if (threads <= 0) {   /* small problems: do not wake more threads than there are 256-body chunks of rows */
+    int cap = n / 256 > 0 ? n / 256 : 1;
+    threads = ref_num_threads() < cap ? ref_num_threads() : cap;
+  }
+  ref_set_num_threads(threads);
   const float dt = 0.01f;
   double total = 0.0, cx = 0, cy = 0, cz = 0;
   if (!fp64) {
