@@ -55,13 +55,18 @@ enum {
   NBODY_OPT_SUM_ORDER = 6, /* NBODY_SUM_* */
   NBODY_OPT_TIMING = 7,    /* 1: HIP events around every force kernel (nbody_kernel_time) */
   NBODY_OPT_COMM = 8,      /* NBODY_COMM_* (multi-GPU) */
-  NBODY_OPT_OVERLAP = 9,   /* multi-GPU: 1 = start on the rank's own slice while the others travel (default), 0 = gather first */
+  NBODY_OPT_OVERLAP = 9,   /* multi-GPU: 1 = start on the rank's own slice while the others travel, then one launch over the
+                              arrived slices (default); 2 = one launch per arriving slice, each released by that slice's
+                              event; 0 = gather first, one launch */
+  NBODY_OPT_SUM_BLOCK = 13, /* NBODY_SUM_BLOCKED: sources per level-1 block (multiple of 64; default 1024) */
+  NBODY_OPT_FUSE_COMBINE = 14, /* 1 (default): the segments' partial sums are added by the last workgroup to arrive, inside
+                              the force launch (one launch per step); 0: a separate combine kernel (same bits) */
   NBODY_OPT_GRAPH = 12,    /* 1 (default): nbody_step on one GPU replays a HIP graph of two steps; 0: launch every kernel */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
   NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: 1 = the product loop (default), 0 = the same instructions placed one 4-byte
                               phase off — 27 % slower, kept so that the code-placement effect can be re-measured */
 };
-enum { NBODY_VARIANT_AUTO = 0,     /* ISA for the timed arithmetic (fp32, FMA3, sequential sum), else SMEM */
+enum { NBODY_VARIANT_AUTO = 0,     /* ISA for the timed arithmetic (fp32, FMA3, blocked or sequential sum), else SMEM */
        NBODY_VARIANT_SMEM = 1,     /* wave-uniform scalar loads (s_load_dwordx16) into SGPRs: no LDS, no VALU cost */
        NBODY_VARIANT_LDS = 2,      /* `tile` bodies staged in LDS per workgroup, broadcast ds_read_b128 */
        NBODY_VARIANT_READLANE = 3, /* 64-body wave tile in VGPRs, v_readlane broadcast ("__shfl") */
@@ -73,15 +78,22 @@ enum { NBODY_ARITH_FMA3 = 0,       /* d2 = fma(dx,dx,fma(dy,dy,fma(dz,dz,eps))):
                                       every operation is then IEEE-exact and the result is bit-identical to the CPU oracle */
        NBODY_ARITH_REFERENCE_STRICT = 3 /* REFERENCE roundings + strict 1/sqrt */ };
 enum { NBODY_SUM_SEQ = 0,          /* one accumulator per segment, sources ascending (S/top_level.vhd:233-254) */
-       NBODY_SUM_FPGA16 = 1        /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */ };
+       NBODY_SUM_FPGA16 = 1,       /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */
+       NBODY_SUM_BLOCKED = 2       /* fp32 DEFAULT, THE TIMED MODE: two levels — blocks of NBODY_OPT_SUM_BLOCK consecutive sources
+                                      are summed from zero, the block sums are added in ascending order.  The reference keeps
+                                      16 partial sums + an adder tree for the same reason (S/fxyz.vhd:129-145,
+                                      S/final_adder.vhd:88-104): one fp32 accumulator over 2^20 terms is off by 1e-4.
+                                      fp64 contexts always sum sequentially. */ };
 enum { NBODY_COMM_RING = 0,        /* P-1 ncclSend/ncclRecv ring steps, one event per arriving slice */
        NBODY_COMM_ALLGATHER = 1,   /* one in-place ncclAllGather (needs N divisible by the rank count, else ring) */
-       NBODY_COMM_AUTO = 2         /* default: ALLGATHER when N divides evenly, RING otherwise */ };
+       NBODY_COMM_AUTO = 2         /* default: RING (the north_star's form) */ };
 
 /* ---- info keys (nbody_get_info) ---- */
 enum { NBODY_INFO_N = 1, NBODY_INFO_N_LOCAL, NBODY_INFO_FIRST_BODY, NBODY_INFO_RANK, NBODY_INFO_NRANKS,
        NBODY_INFO_VARIANT, NBODY_INFO_IBLOCK, NBODY_INFO_JSUB, NBODY_INFO_NSEG, NBODY_INFO_DEVICE,
-       NBODY_INFO_CU_COUNT, NBODY_INFO_CLOCK_KHZ, NBODY_INFO_FP64, NBODY_INFO_TILE, NBODY_INFO_STEPS_DONE };
+       NBODY_INFO_CU_COUNT, NBODY_INFO_CLOCK_KHZ, NBODY_INFO_FP64, NBODY_INFO_TILE, NBODY_INFO_STEPS_DONE,
+       NBODY_INFO_SUM_ORDER, NBODY_INFO_SUM_BLOCK, NBODY_INFO_LAUNCHES_PER_STEP /* kernel launches one nbody_step() step takes */,
+       NBODY_INFO_HAS_COMM /* 1: an RCCL communicator exists */ };
 
 /* ---- lifetime ----
  * Replaces: power-up of the PL design + the ps_pl RAM allocation (S/top_level.vhd:100-117, 148-163). */
@@ -94,6 +106,10 @@ int nbody_init(int n, int ngpus, int fp64, int tile);
  * NBODY_DEVICE, else LOCAL_RANK, else rank modulo the visible device count. */
 int nbody_unique_id(void *uid128);
 int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void *uid128);
+/* Transport self-test on the communicator nbody_init_rank created (uid128 != NULL, any nranks >= 1): an in-place
+ * all-gather of a patterned array in the configured NBODY_OPT_COMM form and one grouped ncclSend/ncclRecv ring step,
+ * every received word checked.  Collective: every rank calls it.  *bytes_moved (may be NULL) = bytes this rank received. */
+int nbody_comm_selftest(long long *bytes_moved);
 void nbody_shutdown(void);
 
 int nbody_set_option(int key, int value);
@@ -135,6 +151,7 @@ int nbody_forces_d(const double *pos_words, double *force_words, int n);
 /* Forces on `n_rows` bodies starting at `first_row`, from the state already on the device
  * (row-sampled parity checks at N = 1M). */
 int nbody_forces_rows(int first_row, int n_rows, float *force_words);
+int nbody_forces_rows_d(int first_row, int n_rows, double *force_words);
 
 /* The reference's mailbox, verbatim: ram_a = (N+1) 16-byte words, word 0 = control
  * {bit 0 BEGIN, bits 46:32 NUM_PTS}; ram_b = N words of forces.  On return word 0 of ram_a has

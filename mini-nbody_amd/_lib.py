@@ -10,13 +10,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libnbody_hip.so")
 
 # mirrors of the enums in include/nbody.h
-OPT_VARIANT, OPT_IBLOCK, OPT_JSUB, OPT_JSLICES, OPT_ARITH, OPT_SUM_ORDER, OPT_TIMING, OPT_COMM, OPT_OVERLAP, OPT_ISA_PHASE, OPT_WAVES_PER_SIMD, OPT_GRAPH = range(1, 13)
+(OPT_VARIANT, OPT_IBLOCK, OPT_JSUB, OPT_JSLICES, OPT_ARITH, OPT_SUM_ORDER, OPT_TIMING, OPT_COMM, OPT_OVERLAP, OPT_ISA_PHASE,
+ OPT_WAVES_PER_SIMD, OPT_GRAPH, OPT_SUM_BLOCK, OPT_FUSE_COMBINE) = range(1, 15)
 VARIANT_AUTO, VARIANT_SMEM, VARIANT_LDS, VARIANT_READLANE, VARIANT_ISA = range(5)
 ARITH_FMA3, ARITH_REFERENCE, ARITH_STRICT, ARITH_REFERENCE_STRICT = 0, 1, 2, 3
-SUM_SEQ, SUM_FPGA16 = 0, 1
+SUM_SEQ, SUM_FPGA16, SUM_BLOCKED = 0, 1, 2
 COMM_RING, COMM_ALLGATHER, COMM_AUTO = 0, 1, 2
 (INFO_N, INFO_N_LOCAL, INFO_FIRST_BODY, INFO_RANK, INFO_NRANKS, INFO_VARIANT, INFO_IBLOCK, INFO_JSUB, INFO_NSEG,
- INFO_DEVICE, INFO_CU_COUNT, INFO_CLOCK_KHZ, INFO_FP64, INFO_TILE, INFO_STEPS_DONE) = range(1, 16)
+ INFO_DEVICE, INFO_CU_COUNT, INFO_CLOCK_KHZ, INFO_FP64, INFO_TILE, INFO_STEPS_DONE, INFO_SUM_ORDER, INFO_SUM_BLOCK,
+ INFO_LAUNCHES_PER_STEP, INFO_HAS_COMM) = range(1, 20)
 
 ERR_NOT_INIT, ERR_ARG, ERR_NO_DEVICE, ERR_RCCL_LOAD, ERR_STATE, ERR_UNSUPPORTED = 1001, 1002, 1003, 1004, 1005, 1006
 
@@ -26,7 +28,7 @@ SYMBOLS = [
     "nbody_error_string", "nbody_upload", "nbody_download", "nbody_upload_d", "nbody_download_d", "bodyForce",
     "integrate", "bodyForce_d", "integrate_d", "nbody_step", "nbody_step_d", "nbody_sync", "nbody_forces",
     "nbody_forces_d", "nbody_forces_rows", "nbody_mailbox_run", "nbody_kernel_time", "nbody_device_ptr",
-    "nbody_set_host_gather", "nbody_download_slice",
+    "nbody_set_host_gather", "nbody_download_slice", "nbody_comm_selftest", "nbody_forces_rows_d",
 ]
 
 
@@ -66,7 +68,8 @@ def load():
         "nbody_upload_d": [C.POINTER(BodySystemD)], "nbody_download_d": [C.POINTER(BodySystemD)],
         "bodyForce": [fp, fp, f, i], "integrate": [fp, fp, f, i], "bodyForce_d": [dp, dp, d, i],
         "integrate_d": [dp, dp, d, i], "nbody_step": [f, i], "nbody_step_d": [d, i], "nbody_sync": [],
-        "nbody_forces": [fp, fp, i], "nbody_forces_d": [dp, dp, i], "nbody_forces_rows": [i, i, fp],
+        "nbody_forces": [fp, fp, i], "nbody_forces_d": [dp, dp, i], "nbody_forces_rows": [i, i, fp], "nbody_forces_rows_d": [i, i, dp],
+        "nbody_comm_selftest": [C.POINTER(C.c_longlong)],
         "nbody_mailbox_run": [vp, vp, i], "nbody_kernel_time": [C.POINTER(d), C.POINTER(C.c_longlong), i],
         "nbody_device_ptr": [i, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "nbody_set_host_gather": [HOST_GATHER_FN, vp], "nbody_download_slice": [vp, vp],

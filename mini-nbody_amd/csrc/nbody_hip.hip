@@ -6,7 +6,8 @@
 //   pos[2]   2 x N words      full position set, double-buffered: a step reads pos[cur] and writes the
 //                             rank's slice of pos[cur^1]; the other slices of pos[cur^1] arrive over xGMI
 //   vel      n_local words    never leaves the rank
-//   partial  nseg x n_local   per-source-segment partial forces (unused when nseg == 1: fused epilogue)
+//   partial  nseg x n_local   per-source-segment partial forces (unused when nseg == 1)
+//   tickets  1 per 256 rows   arrival counters of the in-launch combine (zero between steps)
 //   force    n_local words    last combined forces (mailbox / parity entry points)
 // word = {x,y,z,w}: 16 B (fp32) or 32 B (fp64) — the reference's RAM word, S/top_level.vhd:206-208.
 //
@@ -15,9 +16,10 @@
 // pieces); a step first runs on the rank's own slice while the other slices
 // travel (ring of ncclSend/ncclRecv on a second stream, or peer copies when one
 // process drives all GPUs), then on the arrived slices.  Partial sums are kept
-// per segment and combined in ascending source order, so the result is
-// bit-identical for every arrival order and for a single GPU configured with
-// the same segmentation.
+// per segment and combined in ascending source order — by the last workgroup to
+// arrive for a block of rows, inside the force launch (finish_rows in
+// nbody_kernels.hpp) — so the result is bit-identical for every arrival order
+// and for a single GPU configured with the same segmentation.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types only; the library is resolved with dlopen when nranks > 1
 #include <dlfcn.h>
@@ -81,8 +83,10 @@ struct Local {
   void* pos[2] = {nullptr, nullptr};
   void* vel = nullptr;
   void* partial = nullptr;
+  size_t partial_words = 0;            // capacity of `partial`
+  unsigned* tickets = nullptr;         // one arrival counter per block of 256 rows
   void* force = nullptr;
-  void* vel_full = nullptr;            // download scratch (multi-process)
+  void* full_scratch = nullptr;        // N words: all-gather of a sharded array for the host (multi-process)
   int cur = 0;
   bool all_present = true;             // pos[cur] holds every slice
   hipEvent_t ev_own_ready = nullptr;   // the rank's slice of pos[cur] is written
@@ -97,8 +101,12 @@ struct Local {
 
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
-  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_SEQ, timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1;
+  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_BLOCKED, sum_block = 1024, fuse = 1;
+  int timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1;
 };
+
+// what happens to the force of a row once all its segments are summed
+struct Finish { bool kick, drift, store_force; };
 
 typedef int (*host_gather_fn)(void* user, void* host_words, int n_total, int word_bytes, int rank, int nranks);
 
@@ -118,7 +126,6 @@ struct Global {
   Options opt;
   // resolved launch configuration
   int variant = NBODY_VARIANT_SMEM, R = 4, sub = 1, nslices = 1, nseg = 1;
-  size_t partial_words = 0;
   int cu_count = 0, clock_khz = 0;
   long long steps_done = 0;
 };
@@ -134,13 +141,14 @@ int blocks_for(int rows, int R) { return (rows + kBlock * R - 1) / (kBlock * R);
 // the 8 sources of a scalar-load group across the single chain, and more resident waves hide the transcendental — and
 // cutting the sources into pieces so that a launch has >= 16k workgroups adds ~8 % (load balance across the 256 CUs).
 void resolve_config() {
-  const int n_local = g.loc[0].n_local > 0 ? g.loc[0].n_local : 1;
+  // the largest slice (ceil(N / P)): every rank of a multi-process job resolves the same segmentation from it
+  const int n_local = std::max(1, (g.n + g.nranks - 1) / g.nranks);
   g.nslices = g.nranks > 1 ? g.nranks : (g.opt.jslices > 0 ? g.opt.jslices : 1);
   // AUTO: the hand-scheduled ISA loop (+6 % over hipcc's schedule of the same operations, profiles/r01_sweep_isa.txt)
   g.variant = g.opt.variant == NBODY_VARIANT_AUTO ? NBODY_VARIANT_ISA : g.opt.variant;
   if (g.fp64 && g.variant != NBODY_VARIANT_ISA) g.variant = NBODY_VARIANT_SMEM;   // fp64: ISA loop or the compiled SMEM kernel
   // the hand-scheduled loops exist for the timed arithmetic only; the study modes use the C++ kernels
-  if (g.variant == NBODY_VARIANT_ISA && (g.opt.arith != NBODY_ARITH_FMA3 || g.opt.sum_order != NBODY_SUM_SEQ)) g.variant = NBODY_VARIANT_SMEM;
+  if (g.variant == NBODY_VARIANT_ISA && (g.opt.arith != NBODY_ARITH_FMA3 || g.opt.sum_order == NBODY_SUM_FPGA16)) g.variant = NBODY_VARIANT_SMEM;
   int R = g.opt.iblock;
   if (R == 0) R = (g.variant == NBODY_VARIANT_LDS || g.variant == NBODY_VARIANT_READLANE) ? 2 : 1;
   if (g.variant == NBODY_VARIANT_ISA) R = 1;
@@ -173,6 +181,9 @@ int alloc_local(Local& L) {
   for (int b = 0; b < 2; ++b) { HIPC(hipMalloc(&L.pos[b], (g.n + pad) * wb)); HIPC(hipMemset(L.pos[b], 0, (g.n + pad) * wb)); }
   HIPC(hipMalloc(&L.vel, (L.n_local + pad) * wb));
   HIPC(hipMalloc(&L.force, (L.n_local + pad) * wb));
+  const size_t nt = (size_t)blocks_for(L.n_local, 1) + 16;
+  HIPC(hipMalloc((void**)&L.tickets, nt * sizeof(unsigned)));
+  HIPC(hipMemset(L.tickets, 0, nt * sizeof(unsigned)));
   HIPC(hipMemset(L.vel, 0, (L.n_local + pad) * wb));
   HIPC(hipMemset(L.force, 0, (L.n_local + pad) * wb));
   HIPC(hipEventCreateWithFlags(&L.ev_own_ready, hipEventDisableTiming));
@@ -182,11 +193,12 @@ int alloc_local(Local& L) {
 }
 
 int ensure_partial(Local& L) {
-  size_t need = (size_t)g.nseg * (size_t)L.n_local;
-  if (L.partial && need <= g.partial_words) return NBODY_OK;
+  const size_t need = (size_t)g.nseg * (size_t)L.n_local;
+  if (L.partial && need <= L.partial_words) return NBODY_OK;
   HIPC(hipSetDevice(L.device));
-  if (L.partial) { HIPC(hipFree(L.partial)); L.partial = nullptr; }
+  if (L.partial) { HIPC(hipFree(L.partial)); L.partial = nullptr; L.partial_words = 0; }
   HIPC(hipMalloc(&L.partial, (need + 64) * word_bytes()));
+  L.partial_words = need;
   return NBODY_OK;
 }
 
@@ -198,13 +210,18 @@ void drop_step_graph() {
 int reconfigure() {
   const int o_variant = g.variant, o_R = g.R, o_sub = g.sub, o_nsl = g.nslices;
   resolve_config();
-  if (o_variant != g.variant || o_R != g.R || o_sub != g.sub || o_nsl != g.nslices) drop_step_graph();
-  size_t maxneed = 0;
+  const bool changed = o_variant != g.variant || o_R != g.R || o_sub != g.sub || o_nsl != g.nslices;
+  if (changed) drop_step_graph();
   for (int l = 0; l < g.nlocal; ++l) {
-    NBC(ensure_partial(g.loc[l]));
-    maxneed = std::max(maxneed, (size_t)g.nseg * (size_t)g.loc[l].n_local);
+    Local& L = g.loc[l];
+    NBC(ensure_partial(L));
+    if (changed) {
+      // the arrival counters are zero between steps by construction (the last arriver resets its own); a change of
+      // the row-block shape is the one moment to re-zero them all (stream-ordered with the kernels that use them).
+      HIPC(hipSetDevice(L.device));
+      HIPC(hipMemsetAsync(L.tickets, 0, ((size_t)blocks_for(L.n_local, 1) + 16) * sizeof(unsigned), L.compute));
+    }
   }
-  g.partial_words = std::max(g.partial_words, maxneed);
   return NBODY_OK;
 }
 
@@ -274,23 +291,36 @@ int launch_f32_R(Local& L, dim3 grid, const ForceArgs& a) {
   }
 }
 
-// Launch the force kernel of local L for rows [row0, row0+row_count) against `nsl` source slices
-// starting at slice_start and descending (ring arrival order).  fused only when nseg == 1.
-int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, bool fused, float dt, double dt64) {
-  if (row_count <= 0 || nsl <= 0) return NBODY_OK;
-  HIPC(hipSetDevice(L.device));
-  ForceArgs a;
+// how a launch finishes its rows: directly (one segment), by the last-arriving workgroup, or by combine_kernel
+inline int finish_mode() { return g.nseg == 1 ? kFinishDirect : (g.opt.fuse ? kFinishLast : kFinishStore); }
+
+void fill_args(Local& L, ForceArgs& a, int row0, int row_count, const Finish& fin, float dt, double dt64) {
   memset(&a, 0, sizeof(a));
   a.src = L.pos[L.cur];
   a.rows = word_ptr(L.pos[L.cur], (size_t)L.first);
   a.partial = L.partial;
   a.vel = L.vel;
   a.pos_next_rows = word_ptr(L.pos[L.cur ^ 1], (size_t)L.first);
+  a.force_out = fin.store_force ? L.force : nullptr;
+  a.tickets = L.tickets;
   a.n_src = g.n; a.n_rows = L.n_local; a.row0 = row0; a.row_count = row_count;
-  a.nslices = g.nslices; a.sub = g.sub; a.slice_start = slice_start;
-  a.fused = fused ? 1 : 0;
+  a.nslices = g.nslices; a.sub = g.sub; a.nseg = g.nseg;
+  a.finish = finish_mode();
+  a.do_kick = fin.kick; a.do_drift = fin.drift;
+  a.sum_block = (!g.fp64 && g.opt.sum_order == NBODY_SUM_BLOCKED) ? g.opt.sum_block : 0;
   a.fpga16 = g.opt.sum_order == NBODY_SUM_FPGA16;
   a.dt = dt; a.dt64 = dt64;
+}
+
+// Launch the force kernel of local L for rows [row0, row0+row_count) against `nsl` source slices
+// starting at slice_start and descending (ring arrival order).  A step may take several launches (own slice, then
+// arrived slices); the rows are finished when the LAST of a row block's nseg segments has been summed.
+int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, const Finish& fin, float dt, double dt64) {
+  if (row_count <= 0 || nsl <= 0) return NBODY_OK;
+  HIPC(hipSetDevice(L.device));
+  ForceArgs a;
+  fill_args(L, a, row0, row_count, fin, dt, dt64);
+  a.slice_start = slice_start;
   const int R = g.R;
   dim3 grid(blocks_for(row_count, R), nsl * g.sub, 1);
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
@@ -323,18 +353,12 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, bo
   }
 }
 
-int launch_combine(Local& L, int row0, int row_count, bool kick, bool drift, bool store_force, float dt, double dt64) {
-  if (row_count <= 0) return NBODY_OK;
+// the two-launch form (NBODY_OPT_FUSE_COMBINE = 0): after the step's last force launch, add the partials
+int launch_combine(Local& L, int row0, int row_count, const Finish& fin, float dt, double dt64) {
+  if (row_count <= 0 || finish_mode() != kFinishStore) return NBODY_OK;
   HIPC(hipSetDevice(L.device));
-  CombineArgs c;
-  memset(&c, 0, sizeof(c));
-  c.partial = L.partial;
-  c.pos_rows = word_ptr(L.pos[L.cur], (size_t)L.first);
-  c.pos_next_rows = word_ptr(L.pos[L.cur ^ 1], (size_t)L.first);
-  c.vel = L.vel;
-  c.force_out = store_force ? L.force : nullptr;
-  c.nseg = g.nseg; c.n_rows = L.n_local; c.row0 = row0; c.row_count = row_count;
-  c.do_kick = kick; c.do_drift = drift; c.dt = dt; c.dt64 = dt64;
+  ForceArgs c;
+  fill_args(L, c, row0, row_count, fin, dt, dt64);
   dim3 grid((row_count + kBlock - 1) / kBlock);
   if (g.fp64) hipLaunchKernelGGL((combine_kernel<double, d4>), grid, dim3(kBlock), 0, L.compute, c);
   else hipLaunchKernelGGL((combine_kernel<float, f4>), grid, dim3(kBlock), 0, L.compute, c);
@@ -360,28 +384,39 @@ int host_exchange(Local& L, void* dev_full, int first, int count, bool wait_own_
   return NBODY_OK;
 }
 
-// RCCL all-gather of one sharded device array in place on the comm stream (multi-process): one ncclAllGather when the
-// slices are equal (default), else / on request P-1 ring steps of ncclSend + ncclRecv.  ev[s] (s = 1..P-1), if given,
-// is recorded when ring step s has landed (all of them after the collective in the ncclAllGather form).
+// One ring step on the comm stream: send `send_bytes` at `send_ptr` to the next rank, receive `recv_bytes` at `recv_ptr`
+// from the previous one, as one RCCL group (so neither side blocks the other).  With one rank next = prev = self and the
+// pair is a device-local copy through RCCL (what nbody_comm_selftest runs on a one-GPU box).
+int ring_step(Local& L, const void* send_ptr, size_t send_bytes, void* recv_ptr, size_t recv_bytes) {
+  const int P = g.nranks;
+  const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
+  NCCLC(g_rccl.GroupStart());
+  NCCLC(g_rccl.Send(send_ptr, send_bytes, ncclChar, next, L.comm_h, L.comm));
+  NCCLC(g_rccl.Recv(recv_ptr, recv_bytes, ncclChar, prev, L.comm_h, L.comm));
+  NCCLC(g_rccl.GroupEnd());
+  return NBODY_OK;
+}
+
+// RCCL all-gather of one sharded device array in place on the comm stream (multi-process).  Default (NBODY_COMM_AUTO,
+// NBODY_COMM_RING): the north_star's ring — P-1 steps, step s forwards the slice that arrived at step s-1 (the rank's
+// own at s = 1) and receives slice (rank - s) mod P; ev[s], if given, is recorded as soon as that slice has landed, so
+// the force kernel over it can start while the next one travels.  NBODY_COMM_ALLGATHER: one in-place ncclAllGather
+// (equal slices only; all events after the collective).
 int rccl_gather(Local& L, void* dev_full, hipEvent_t* ev) {
   const int P = g.nranks;
   const size_t wb = word_bytes();
   const bool even = (g.n % P) == 0;
-  if (even && (g.opt.comm == NBODY_COMM_ALLGATHER || g.opt.comm == NBODY_COMM_AUTO)) {
+  if (even && g.opt.comm == NBODY_COMM_ALLGATHER) {
     NCCLC(g_rccl.AllGather(word_ptr(dev_full, L.first), dev_full, (size_t)L.n_local * wb, ncclChar, L.comm_h, L.comm));
     if (ev) for (int s = 1; s < P; ++s) HIPC(hipEventRecord(ev[s], L.comm));
     return NBODY_OK;
   }
-  const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
   for (int s = 1; s < P; ++s) {
     const int qs = ring_slice(L.rank, s - 1);   // forward what arrived last (own slice at s = 1)
     const int qr = ring_slice(L.rank, s);
     const int fs = slice_first(qs, g.n, P), ls = slice_first(qs + 1, g.n, P) - fs;
     const int fr = slice_first(qr, g.n, P), lr = slice_first(qr + 1, g.n, P) - fr;
-    NCCLC(g_rccl.GroupStart());
-    NCCLC(g_rccl.Send(word_ptr(dev_full, fs), (size_t)ls * wb, ncclChar, next, L.comm_h, L.comm));
-    NCCLC(g_rccl.Recv(word_ptr(dev_full, fr), (size_t)lr * wb, ncclChar, prev, L.comm_h, L.comm));
-    NCCLC(g_rccl.GroupEnd());
+    NBC(ring_step(L, word_ptr(dev_full, fs), (size_t)ls * wb, word_ptr(dev_full, fr), (size_t)lr * wb));
     if (ev) HIPC(hipEventRecord(ev[s], L.comm));
   }
   return NBODY_OK;
@@ -425,11 +460,11 @@ int enqueue_gather(int buf) {
 // One step on every local: forces on pos[cur], kick, drift into pos[cur^1], swap.
 int enqueue_step(float dt, double dt64) {
   const int P = g.nranks;
-  const bool fused = (g.nseg == 1);
+  const Finish fin = {true, true, false};
   const bool need_gather = !g.loc[0].all_present;
   if (need_gather && g.opt.overlap) {
     // own slice first: these kernels run while the other slices travel (second stream / host-staged exchange)
-    for (int l = 0; l < g.nlocal; ++l) NBC(launch_force(g.loc[l], 0, g.loc[l].n_local, g.loc[l].rank, 1, false, dt, dt64));
+    for (int l = 0; l < g.nlocal; ++l) NBC(launch_force(g.loc[l], 0, g.loc[l].n_local, g.loc[l].rank, 1, fin, dt, dt64));
     NBC(enqueue_gather(g.loc[0].cur));
   }
   for (int l = 0; l < g.nlocal; ++l) {
@@ -440,19 +475,25 @@ int enqueue_step(float dt, double dt64) {
       if (l == 0) NBC(enqueue_gather(L.cur));
     }
     if (P == 1) {
-      NBC(launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fused, dt, dt64));
+      NBC(launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fin, dt, dt64));
     } else if (!need_gather) {
-      NBC(launch_force(L, 0, L.n_local, L.rank, P, false, dt, dt64));
+      NBC(launch_force(L, 0, L.n_local, L.rank, P, fin, dt, dt64));
+    } else if (g.opt.overlap == 2) {
+      // one launch per arriving slice, each released by that slice's event (ring arrival order)
+      for (int s = 1; s < P; ++s) {
+        HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[s], 0));
+        NBC(launch_force(L, 0, L.n_local, ring_slice(L.rank, s), 1, fin, dt, dt64));
+      }
     } else if (g.opt.overlap) {
-      // the other slices once they have all arrived (one launch: the transfer is ~100 us against
-      // milliseconds of own-slice work already running)
+      // the other slices in one launch once they have all arrived (at N = 1M the ring takes ~0.4 ms against
+      // ~4 ms of own-slice work already running)
       HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[P - 1], 0));
-      NBC(launch_force(L, 0, L.n_local, ring_slice(L.rank, 1), P - 1, false, dt, dt64));
+      NBC(launch_force(L, 0, L.n_local, ring_slice(L.rank, 1), P - 1, fin, dt, dt64));
     } else {
       HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[P - 1], 0));
-      NBC(launch_force(L, 0, L.n_local, L.rank, P, false, dt, dt64));
+      NBC(launch_force(L, 0, L.n_local, L.rank, P, fin, dt, dt64));
     }
-    if (!fused) NBC(launch_combine(L, 0, L.n_local, true, true, false, dt, dt64));
+    NBC(launch_combine(L, 0, L.n_local, fin, dt, dt64));
     HIPC(hipEventRecord(L.ev_own_ready, L.compute));
   }
   for (int l = 0; l < g.nlocal; ++l) {
@@ -502,7 +543,7 @@ int init_common(int n, int fp64, int tile) {
   if (tile == 0) tile = 256;
   if (tile < 64 || tile > 1024 || tile % 64) return NBODY_ERR_ARG;
   g.n = n; g.fp64 = fp64 ? 1 : 0; g.tile = tile;
-  g.steps_done = 0; g.partial_words = 0;
+  g.steps_done = 0;
   return NBODY_OK;
 }
 
@@ -522,7 +563,8 @@ void free_local(Local& L) {
   if (L.vel) (void)hipFree(L.vel);
   if (L.partial) (void)hipFree(L.partial);
   if (L.force) (void)hipFree(L.force);
-  if (L.vel_full) (void)hipFree(L.vel_full);
+  if (L.tickets) (void)hipFree(L.tickets);
+  if (L.full_scratch) (void)hipFree(L.full_scratch);
   if (L.ev_own_ready) (void)hipEventDestroy(L.ev_own_ready);
   for (int s = 0; s < kMaxRanks; ++s) if (L.ev_gather[s]) (void)hipEventDestroy(L.ev_gather[s]);
   for (int k = 0; k < kTimerRing; ++k) { if (L.t0[k]) (void)hipEventDestroy(L.t0[k]); if (L.t1[k]) (void)hipEventDestroy(L.t1[k]); }
@@ -547,18 +589,21 @@ int upload_impl(const void* pos, const void* vel) {
   return sync_all();
 }
 
-int gather_vel_multiprocess(Local& L) {
+// Multi-process: all-gather a rank-sharded array (n_local words on every rank: velocities, forces) into
+// L.full_scratch (N words) with the transport in use.  The compute stream must be idle.
+int gather_sharded_multiprocess(Local& L, const void* own_rows) {
   const size_t wb = word_bytes();
   HIPC(hipSetDevice(L.device));
-  if (!L.vel_full) HIPC(hipMalloc(&L.vel_full, (size_t)(g.n + 64) * wb));
-  HIPC(hipMemcpyAsync(word_ptr(L.vel_full, L.first), L.vel, (size_t)L.n_local * wb, hipMemcpyDeviceToDevice, L.comm));
+  if (!L.full_scratch) HIPC(hipMalloc(&L.full_scratch, (size_t)(g.n + 64) * wb));
+  HIPC(hipMemcpyAsync(word_ptr(L.full_scratch, L.first), own_rows, (size_t)L.n_local * wb, hipMemcpyDeviceToDevice, L.comm));
   if (g.host_gather) {
     HIPC(hipStreamSynchronize(L.comm));
-    NBC(host_exchange(L, L.vel_full, L.first, L.n_local, false));
+    NBC(host_exchange(L, L.full_scratch, L.first, L.n_local, false));
     HIPC(hipStreamSynchronize(L.comm));
     return NBODY_OK;
   }
-  NBC(rccl_gather(L, L.vel_full, nullptr));
+  if (!L.comm_h) return NBODY_ERR_STATE;
+  NBC(rccl_gather(L, L.full_scratch, nullptr));
   HIPC(hipStreamSynchronize(L.comm));
   return NBODY_OK;
 }
@@ -571,9 +616,9 @@ int download_impl(void* pos, void* vel) {
   if (g.multiprocess && g.nranks > 1) {
     Local& L = g.loc[0];
     NBC(complete_positions());
-    NBC(gather_vel_multiprocess(L));
+    NBC(gather_sharded_multiprocess(L, L.vel));
     HIPC(hipMemcpy(pos, L.pos[L.cur], (size_t)g.n * wb, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(vel, L.vel_full, (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(vel, L.full_scratch, (size_t)g.n * wb, hipMemcpyDeviceToHost));
     return NBODY_OK;
   }
   for (int l = 0; l < g.nlocal; ++l) {
@@ -593,8 +638,9 @@ int forces_on_device(int row0, int count_or_all) {
     Local& L = g.loc[l];
     int cnt = count_or_all < 0 ? L.n_local : count_or_all;
     int r0 = count_or_all < 0 ? 0 : row0;
-    NBC(launch_force(L, r0, cnt, g.nslices - 1, g.nslices, false, 0.f, 0.0));
-    NBC(launch_combine(L, r0, cnt, false, false, true, 0.f, 0.0));
+    const Finish fin = {false, false, true};
+    NBC(launch_force(L, r0, cnt, g.nslices - 1, g.nslices, fin, 0.f, 0.0));
+    NBC(launch_combine(L, r0, cnt, fin, 0.f, 0.0));
   }
   return sync_all();
 }
@@ -613,13 +659,16 @@ int step_impl(float dt, double dt64, int nsteps) {
       drop_step_graph();
       hipGraph_t graph = nullptr;
       const long long done = g.steps_done;
+      const int cur0 = L.cur;
+      const bool present0 = L.all_present;
       HIPC(hipStreamBeginCapture(L.compute, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_step(dt, dt64);
       if (!rc) rc = enqueue_step(dt, dt64);
       hipError_t e = hipStreamEndCapture(L.compute, &graph);
       g.steps_done = done;                       // capturing executes nothing
+      L.cur = cur0; L.all_present = present0;    // two steps return to the same buffer; a failed capture may have toggled once
       if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      HIPC(e);
+      if (e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); g_last_line = __LINE__; return (int)e; }
       e = hipGraphInstantiate(&g.step_graph, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIPC(e);
@@ -638,16 +687,17 @@ int body_force_impl(void* pos, void* vel, float dt, double dt64, int n) {
   NBC(reconfigure());
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
-    NBC(launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, false, dt, dt64));
-    NBC(launch_combine(L, 0, L.n_local, true, false, true, dt, dt64));
+    const Finish fin = {true, false, true};
+    NBC(launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fin, dt, dt64));
+    NBC(launch_combine(L, 0, L.n_local, fin, dt, dt64));
   }
   NBC(sync_all());
   // vel back (pos is read-only for bodyForce)
   const size_t wb = word_bytes();
   if (g.multiprocess && g.nranks > 1) {
     Local& L = g.loc[0];
-    NBC(gather_vel_multiprocess(L));
-    HIPC(hipMemcpy(vel, L.vel_full, (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    NBC(gather_sharded_multiprocess(L, L.vel));
+    HIPC(hipMemcpy(vel, L.full_scratch, (size_t)g.n * wb, hipMemcpyDeviceToHost));
     return NBODY_OK;
   }
   for (int l = 0; l < g.nlocal; ++l) {
@@ -695,7 +745,6 @@ int integrate_impl(void* pos, const void* vel, float dt, double dt64, int n) {
 int forces_impl(const void* pos_words, void* force_words, int n) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (n != g.n || !pos_words || !force_words) return NBODY_ERR_ARG;
-  if (g.multiprocess && g.nranks > 1) return NBODY_ERR_UNSUPPORTED;   // force words of other processes are not gathered
   const size_t wb = word_bytes();
   NBC(sync_all());
   for (int l = 0; l < g.nlocal; ++l) {
@@ -705,6 +754,12 @@ int forces_impl(const void* pos_words, void* force_words, int n) {
     L.all_present = true;
   }
   NBC(forces_on_device(0, -1));
+  if (g.multiprocess && g.nranks > 1) {   // every process returns all N force words: gather the other ranks' rows
+    Local& L = g.loc[0];
+    NBC(gather_sharded_multiprocess(L, L.force));
+    HIPC(hipMemcpy(force_words, L.full_scratch, (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+  }
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
     HIPC(hipSetDevice(L.device));
@@ -712,6 +767,23 @@ int forces_impl(const void* pos_words, void* force_words, int n) {
   }
   return NBODY_OK;
 }
+
+int forces_rows_impl(int first_row, int n_rows, void* force_words) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (g.nlocal != 1 || !force_words) return NBODY_ERR_UNSUPPORTED;
+  Local& L = g.loc[0];
+  if (first_row < 0 || n_rows <= 0 || first_row + n_rows > L.n_local) return NBODY_ERR_ARG;
+  NBC(forces_on_device(first_row, n_rows));
+  HIPC(hipSetDevice(L.device));
+  HIPC(hipMemcpy(force_words, word_ptr(L.force, first_row), (size_t)n_rows * word_bytes(), hipMemcpyDeviceToHost));
+  return NBODY_OK;
+}
+
+// two HIP events that are destroyed on every way out
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
 
 }  // namespace
 
@@ -741,7 +813,10 @@ int nbody_init(int n, int ngpus, int fp64, int tile) {
     int e = alloc_local(L);
     if (e) { nbody_shutdown(); return e; }
   }
-  HIPC(hipGetDeviceProperties(&prop, g.loc[0].device));
+  {
+    hipError_t pe = hipGetDeviceProperties(&prop, g.loc[0].device);
+    if (pe != hipSuccess) { g_last_line = __LINE__; nbody_shutdown(); return (int)pe; }
+  }
   g.cu_count = prop.multiProcessorCount; g.clock_khz = prop.clockRate;
   if (ngpus > 1) {
     for (int a = 0; a < ngpus; ++a)
@@ -786,16 +861,22 @@ int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void*
   int e = alloc_local(L);
   if (e) { nbody_shutdown(); return e; }
   hipDeviceProp_t prop;
-  HIPC(hipGetDeviceProperties(&prop, L.device));
+  {
+    hipError_t pe = hipGetDeviceProperties(&prop, L.device);
+    if (pe != hipSuccess) { g_last_line = __LINE__; nbody_shutdown(); return (int)pe; }
+  }
   g.cu_count = prop.multiProcessorCount; g.clock_khz = prop.clockRate;
-  if (nranks > 1 && uid128) {
+  if (uid128) {
+    // a communicator is created whenever an id is given — also for nranks = 1, where it carries no traffic in a step
+    // but lets nbody_comm_selftest() push bytes through the same RCCL calls the multi-GPU job makes
     e = rccl_load();
     if (e) { nbody_shutdown(); return e; }
     ncclUniqueId id;
     memcpy(&id, uid128, sizeof(id));
-    HIPC(hipSetDevice(L.device));
+    hipError_t de = hipSetDevice(L.device);
+    if (de != hipSuccess) { g_last_line = __LINE__; nbody_shutdown(); return (int)de; }
     ncclResult_t r = g_rccl.CommInitRank(&L.comm_h, nranks, id, rank);
-    if (r != ncclSuccess) { nbody_shutdown(); return 2000 + (int)r; }
+    if (r != ncclSuccess) { g_last_line = __LINE__; L.comm_h = nullptr; nbody_shutdown(); return 2000 + (int)r; }
   }
   g.init = true;
   g.opt = Options();
@@ -804,12 +885,60 @@ int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void*
   if (nranks > 1 && L.comm_h) {
     // One all-gather of the (zeroed) position buffer now: RCCL sets up its rings/channels lazily on the first
     // collective, and that must not land in a caller's first timed step.
-    HIPC(hipSetDevice(L.device));
-    HIPC(hipEventRecord(L.ev_own_ready, L.compute));
-    e = enqueue_gather(L.cur);
+    hipError_t he = hipSetDevice(L.device);
+    if (he == hipSuccess) he = hipEventRecord(L.ev_own_ready, L.compute);
+    e = he != hipSuccess ? (int)he : enqueue_gather(L.cur);
     if (!e) e = sync_all();
     if (e) { nbody_shutdown(); return e; }
   }
+  return NBODY_OK;
+}
+
+// Transport self-test on the communicator of nbody_init_rank: (1) an in-place all-gather of a patterned scratch array
+// through rccl_gather() in the configured NBODY_OPT_COMM form, (2) one ring step (ncclSend to rank+1, ncclRecv from
+// rank-1, grouped) of a patterned block — with one rank both are device-local, which is how a one-GPU box exercises
+// the library's RCCL calls (symbols, argument order, byte counts).  Every received word is checked on the host.
+int nbody_comm_selftest(long long* bytes_moved) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!g.multiprocess) return NBODY_ERR_STATE;
+  Local& L = g.loc[0];
+  if (!L.comm_h) return NBODY_ERR_STATE;
+  NBC(sync_all());
+  const size_t wb = word_bytes();
+  const int P = g.nranks;
+  HIPC(hipSetDevice(L.device));
+  if (!L.full_scratch) HIPC(hipMalloc(&L.full_scratch, (size_t)(g.n + 64) * wb));
+  // (1) all-gather: word w of rank q's slice = q * 2^24 + (w mod 2^24), in every 4-byte lane of the word
+  std::vector<uint32_t> host((size_t)g.n * (wb / 4));
+  HIPC(hipMemset(L.full_scratch, 0xff, (size_t)g.n * wb));
+  for (int w = L.first; w < L.first + L.n_local; ++w)
+    for (size_t k = 0; k < wb / 4; ++k) host[(size_t)w * (wb / 4) + k] = ((uint32_t)L.rank << 24) + ((uint32_t)w & 0xffffffu);
+  HIPC(hipMemcpy(word_ptr(L.full_scratch, L.first), &host[(size_t)L.first * (wb / 4)], (size_t)L.n_local * wb, hipMemcpyHostToDevice));
+  NBC(rccl_gather(L, L.full_scratch, nullptr));
+  HIPC(hipStreamSynchronize(L.comm));
+  HIPC(hipMemcpy(host.data(), L.full_scratch, (size_t)g.n * wb, hipMemcpyDeviceToHost));
+  for (int q = 0; q < P; ++q)
+    for (int w = slice_first(q, g.n, P); w < slice_first(q + 1, g.n, P); ++w)
+      for (size_t k = 0; k < wb / 4; ++k)
+        if (host[(size_t)w * (wb / 4) + k] != ((uint32_t)q << 24) + ((uint32_t)w & 0xffffffu)) { g_last_line = __LINE__; return NBODY_ERR_STATE; }
+  long long moved = (long long)(g.n - L.n_local) * (long long)wb;
+  // (2) one ring step: the first half of the scratch array goes to rank+1, the second half is received from rank-1
+  const int half = g.n / 2;
+  if (half > 0) {
+    const int prev = (L.rank + P - 1) % P;
+    for (int w = 0; w < half; ++w)
+      for (size_t k = 0; k < wb / 4; ++k) host[(size_t)w * (wb / 4) + k] = 0xA5000000u + ((uint32_t)L.rank << 20) + ((uint32_t)w & 0xfffffu);
+    HIPC(hipMemcpy(L.full_scratch, host.data(), (size_t)half * wb, hipMemcpyHostToDevice));
+    HIPC(hipMemset(word_ptr(L.full_scratch, half), 0, (size_t)half * wb));
+    NBC(ring_step(L, L.full_scratch, (size_t)half * wb, word_ptr(L.full_scratch, half), (size_t)half * wb));
+    HIPC(hipStreamSynchronize(L.comm));
+    HIPC(hipMemcpy(host.data(), word_ptr(L.full_scratch, half), (size_t)half * wb, hipMemcpyDeviceToHost));
+    for (int w = 0; w < half; ++w)
+      for (size_t k = 0; k < wb / 4; ++k)
+        if (host[(size_t)w * (wb / 4) + k] != 0xA5000000u + ((uint32_t)prev << 20) + ((uint32_t)w & 0xfffffu)) { g_last_line = __LINE__; return NBODY_ERR_STATE; }
+    moved += (long long)half * (long long)wb;
+  }
+  if (bytes_moved) *bytes_moved = moved;
   return NBODY_OK;
 }
 
@@ -818,7 +947,7 @@ void nbody_shutdown(void) {
   for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);
   if (g.host_stage) { (void)hipHostFree(g.host_stage); g.host_stage = nullptr; }
   g.host_gather = nullptr; g.host_gather_user = nullptr;
-  g.init = false; g.nlocal = 0; g.nranks = 1; g.partial_words = 0;
+  g.init = false; g.nlocal = 0; g.nranks = 1;
 }
 
 int nbody_set_option(int key, int value) {
@@ -828,10 +957,12 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_JSUB: if (value < 0 || value > 256) return NBODY_ERR_ARG; g.opt.jsub = value; break;
     case NBODY_OPT_JSLICES: if (value < 0 || value > kMaxRanks) return NBODY_ERR_ARG; g.opt.jslices = value; break;
     case NBODY_OPT_ARITH: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.arith = value; break;
-    case NBODY_OPT_SUM_ORDER: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.sum_order = value; break;
+    case NBODY_OPT_SUM_ORDER: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.sum_order = value; break;
+    case NBODY_OPT_SUM_BLOCK: if (value < 8 || value > (1 << 24) || value % 64) return NBODY_ERR_ARG; g.opt.sum_block = value; break;
+    case NBODY_OPT_FUSE_COMBINE: g.opt.fuse = value ? 1 : 0; break;
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
     case NBODY_OPT_COMM: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.comm = value; break;
-    case NBODY_OPT_OVERLAP: g.opt.overlap = value ? 1 : 0; break;
+    case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;
     case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
     case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
@@ -861,6 +992,14 @@ int nbody_get_info(int key, long long* value) {
     case NBODY_INFO_FP64: *value = g.fp64; break;
     case NBODY_INFO_TILE: *value = g.tile; break;
     case NBODY_INFO_STEPS_DONE: *value = g.steps_done; break;
+    case NBODY_INFO_SUM_ORDER: *value = g.fp64 ? NBODY_SUM_SEQ : g.opt.sum_order; break;
+    case NBODY_INFO_SUM_BLOCK: *value = (!g.fp64 && g.opt.sum_order == NBODY_SUM_BLOCKED) ? g.opt.sum_block : 0; break;
+    case NBODY_INFO_LAUNCHES_PER_STEP: {
+      const int force = g.nranks == 1 ? 1 : (g.opt.overlap == 2 ? g.nranks : (g.opt.overlap ? 2 : 1));
+      *value = force + (finish_mode() == kFinishStore ? 1 : 0);
+      break;
+    }
+    case NBODY_INFO_HAS_COMM: *value = L.comm_h ? 1 : 0; break;
     default: return NBODY_ERR_ARG;
   }
   return NBODY_OK;
@@ -914,16 +1053,8 @@ int nbody_sync(void) { if (!g.init) return NBODY_ERR_NOT_INIT; return sync_all()
 int nbody_forces(const float* pos_words, float* force_words, int n) { if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
 int nbody_forces_d(const double* pos_words, double* force_words, int n) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
 
-int nbody_forces_rows(int first_row, int n_rows, float* force_words) {
-  if (!g.init) return NBODY_ERR_NOT_INIT;
-  if (g.fp64 || g.nlocal != 1 || !force_words) return NBODY_ERR_UNSUPPORTED;
-  Local& L = g.loc[0];
-  if (first_row < 0 || n_rows <= 0 || first_row + n_rows > L.n_local) return NBODY_ERR_ARG;
-  NBC(forces_on_device(first_row, n_rows));
-  HIPC(hipSetDevice(L.device));
-  HIPC(hipMemcpy(force_words, word_ptr(L.force, first_row), (size_t)n_rows * word_bytes(), hipMemcpyDeviceToHost));
-  return NBODY_OK;
-}
+int nbody_forces_rows(int first_row, int n_rows, float* force_words) { if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
+int nbody_forces_rows_d(int first_row, int n_rows, double* force_words) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
 
 int nbody_mailbox_run(void* ram_a, void* ram_b, int clock_khz) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
@@ -933,18 +1064,16 @@ int nbody_mailbox_run(void* ram_a, void* ram_b, int clock_khz) {
   if (!(w0[0] & 1u)) return NBODY_ERR_STATE;
   const int num_pts = (int)(w0[1] & 0x7FFFu);
   if (num_pts != g.n) return NBODY_ERR_ARG;
-  hipEvent_t e0, e1;
+  EventPair ev;   // destroyed on every exit
   HIPC(hipSetDevice(g.loc[0].device));
-  HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
-  HIPC(hipEventRecord(e0, g.loc[0].compute));
+  HIPC(hipEventCreate(&ev.e0)); HIPC(hipEventCreate(&ev.e1));
+  HIPC(hipEventRecord(ev.e0, g.loc[0].compute));
   // bodies are words 1..N                                              S/top_level.vhd:55, 206-208
-  int rc = forces_impl((const float*)ram_a + 4, (float*)ram_b, num_pts);
-  HIPC(hipEventRecord(e1, g.loc[0].compute));
-  HIPC(hipEventSynchronize(e1));
+  NBC(forces_impl((const float*)ram_a + 4, (float*)ram_b, num_pts));
+  HIPC(hipEventRecord(ev.e1, g.loc[0].compute));
+  HIPC(hipEventSynchronize(ev.e1));
   float ms = 0.f;
-  HIPC(hipEventElapsedTime(&ms, e0, e1));
-  HIPC(hipEventDestroy(e0)); HIPC(hipEventDestroy(e1));
-  if (rc) return rc;
+  HIPC(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   // completion: word 0 <- {ticks in [63:32], 0 elsewhere}: BEGIN reads 0  S/top_level.vhd:146, 255-263
   // one tick = 1000 clocks (S/top_level.vhd:121-144); the counter starts at 1 on BEGIN's rising edge (:138-139)
   const double khz = clock_khz > 0 ? (double)clock_khz : 300000.0;

@@ -20,8 +20,19 @@
 //   SMEM      wave-uniform scalar loads into SGPRs; VALU reads them as scalar operands (free)
 //   LDS       TILE bodies staged in LDS, every lane reads the same address (broadcast ds_read_b128)
 //   READLANE  each lane holds one body of a 64-body wave tile; v_readlane_b32 x3 per source (4 cycles each)
-// All of them add the sources of a segment in ascending j into one accumulator
-// per axis, so they return identical bits.
+// All of them add the sources of a segment in the same order, so they return
+// identical bits.  The order inside a segment (ForceArgs::sum_block = K > 0, the default K = 1024): level 1 sums a
+// block of K consecutive sources from zero with one fma per term (S/fxyz.vhd:120-127), level 2 adds the finished
+// block sums in ascending order into a second accumulator.  The reference does not run one long sequential sum
+// either — it keeps 16 partial sums and joins them with an adder tree (S/fxyz.vhd:129-145, S/final_adder.vhd:88-104) —
+// and for the same reason: at N = 2^20 a single fp32 accumulator is off by 1e-4 of the force, the two-level sum by
+// 3e-7 (profiles/r02_error_budget.md).  Cost: 3 v_add + 7 v_mov per 12288 VALU instructions.  K = 0 keeps the plain
+// sequential sum (study mode; what a CPU nbody.c does).
+//
+// How a row's force is finished (ForceArgs::finish): with one segment the kernel applies kick and drift itself;
+// with several, every workgroup stores its partial sum and the LAST workgroup to arrive for a block of rows (an
+// agent-scope ticket per row block) adds the partials in ascending segment order and applies kick and drift — one
+// launch per step, and the result does not depend on which workgroup came last.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,19 +49,28 @@ constexpr uint32_t kSoftBits = 0x3089705Fu;  // S/dzsoft.vhd:177
 // always selected as s_load_* (scalar cache), never as a vector load.
 #define NB_CONST __attribute__((address_space(4)))
 
+constexpr int kFinishStore = 0;    // store the segment's partial sum; combine_kernel follows
+constexpr int kFinishDirect = 1;   // one segment: the kernel's own sum is the force
+constexpr int kFinishLast = 2;     // store the partial sum (write-through); the last workgroup to arrive combines
+
 struct ForceArgs {
   const void* src;      // all N source bodies (16-B or 32-B words), ascending
   const void* rows;     // the rank's own bodies: rows[i] = src[first_body + i]
   void* partial;        // [nseg][n_rows] words {Fx,Fy,Fz,0}
-  void* vel;            // [n_rows] (fused epilogue only)
-  void* pos_next_rows;  // [n_rows] (fused epilogue only)
+  void* vel;            // [n_rows]
+  void* pos_next_rows;  // [n_rows]
+  void* force_out;      // [n_rows] {Fx,Fy,Fz,0} (S/compute_store.vhd:242) or null
+  unsigned* tickets;    // one counter per block of rows (kFinishLast), zero between steps
   int n_src;            // N
   int n_rows;           // bodies owned by this rank
   int row0;             // first row handled by this launch (nbody_forces_rows)
   int row_count;        // rows handled by this launch
   int nslices, sub;     // segmentation of the sources: nslices slices (one per rank), `sub` pieces each
   int slice_start;      // blockIdx.y / sub = 0 maps to this slice; then descending modulo nslices (ring arrival order)
-  int fused;            // 1: nseg == 1, apply kick and drift here
+  int nseg;             // nslices * sub: partial sums per row once every launch of the step has run
+  int finish;           // kFinish*
+  int do_kick, do_drift;  // what to do with the finished force: v += dt*F, then r' = r + v*dt
+  int sum_block;        // K sources per level-1 block; 0 = one sequential sum per segment
   int fpga16;           // 1: S/fxyz.vhd:129-184 + S/final_adder.vhd:88-104 summation order inside a segment
   float dt;
   double dt64;
@@ -147,28 +167,186 @@ __device__ __forceinline__ float tree16(const float* p) {
 }
 
 // ---------------------------------------------------------------------------
-// epilogue shared by the fp32 kernels: either store the segment's partial sum or
-// (single segment) apply the kick v += dt*F and the drift r += v*dt in place.
-__device__ __forceinline__ void epilogue_f32(const ForceArgs& a, int seg, int i, float xi, float yi, float zi, float wi,
-                                             float ax, float ay, float az) {
-  if (a.fused) {
-    f4* vel = (f4*)a.vel;
-    f4* pn = (f4*)a.pos_next_rows;
-    f4 v = vel[i];
-    v.x = __builtin_fmaf(a.dt, ax, v.x);
-    v.y = __builtin_fmaf(a.dt, ay, v.y);
-    v.z = __builtin_fmaf(a.dt, az, v.z);
-    vel[i] = v;
-    f4 p;
-    p.x = __builtin_fmaf(v.x, a.dt, xi);
-    p.y = __builtin_fmaf(v.y, a.dt, yi);
-    p.z = __builtin_fmaf(v.z, a.dt, zi);
-    p.w = wi;
-    pn[i] = p;
-  } else {
-    f4 o = {ax, ay, az, 0.0f};   // S/compute_store.vhd:242 {0, Fz, Fy, Fx}
-    ((f4*)a.partial)[(size_t)seg * a.n_rows + i] = o;
+// Level-1 / level-2 accumulators of R rows.
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename T, int R>
+struct Sums {
+  T ax[R], ay[R], az[R];   // level 1: the running block
+  T bx[R], by[R], bz[R];   // level 2: finished blocks
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ax[r] = ay[r] = az[r] = (T)0; bx[r] = by[r] = bz[r] = (T)0; }
   }
+  __device__ __forceinline__ void fold() {   // a block is finished
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      bx[r] = bx[r] + ax[r]; by[r] = by[r] + ay[r]; bz[r] = bz[r] + az[r];
+      ax[r] = ay[r] = az[r] = (T)0;
+    }
+  }
+  // the segment's sum: sequential mode = level 1 itself; blocked mode = level 2 after the last (partial) block
+  __device__ __forceinline__ void close(bool blocked, bool open_block) {
+    if (!blocked) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { bx[r] = ax[r]; by[r] = ay[r]; bz[r] = az[r]; }
+    } else if (open_block) {
+      fold();
+    }
+  }
+};
+
+// Walks a segment [jb, je) block by block: body(j0, j1) must add the sources [j0, j1) in ascending order to level 1.
+template <typename T, int R, typename Body>
+__device__ __forceinline__ void walk_blocks(const ForceArgs& a, int jb, int je, Sums<T, R>& s, Body body) {
+  if (a.sum_block <= 0) { body(jb, je); s.close(false, false); return; }
+  int j0 = jb;
+  for (; j0 + a.sum_block <= je; j0 += a.sum_block) { body(j0, j0 + a.sum_block); s.fold(); }
+  if (j0 < je) body(j0, je);
+  s.close(true, j0 < je);
+}
+
+// ---------------------------------------------------------------------------
+// What happens to a finished force (S/compute_store.vhd:203-242 writes {Fx,Fy,Fz,0}; kick and drift are the
+// north_star's bodyForce()/integrate(), one rounding each).
+template <typename T, typename V4, typename Args>
+__device__ __forceinline__ void apply_force(const Args& a, int i, V4 me, T fx, T fy, T fz) {
+  if (a.force_out) { V4 o = {fx, fy, fz, (T)0}; ((V4*)a.force_out)[i] = o; }
+  if (a.do_kick) {
+    const T dt = sizeof(T) == 8 ? (T)a.dt64 : (T)a.dt;
+    V4* vel = (V4*)a.vel;
+    V4 v = vel[i];
+    v.x = fma_t(dt, fx, v.x); v.y = fma_t(dt, fy, v.y); v.z = fma_t(dt, fz, v.z);
+    vel[i] = v;
+    if (a.do_drift) {
+      V4 p;
+      p.x = fma_t(v.x, dt, me.x); p.y = fma_t(v.y, dt, me.y); p.z = fma_t(v.z, dt, me.z);
+      p.w = me.w;
+      ((V4*)a.pos_next_rows)[i] = p;
+    }
+  }
+}
+
+// 16-B write-through (sc1) stores and L1-bypassing (sc1) loads of one {x,y,z,w} word through a buffer descriptor:
+// the hand-off between workgroups below moves its payload with nothing else (MI355X_MICROARCH.md, inter-workgroup
+// visibility: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by other CUs' stores).
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+struct u4x2 { u4 lo, hi; };
+template <typename V4>
+__device__ __forceinline__ void store_word_sc1(__amdgpu_buffer_rsrc_t rs, int off, V4 v) {
+  if constexpr (sizeof(V4) == 16) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, off, 0, 16);
+  } else {
+    u4x2 t = __builtin_bit_cast(u4x2, v);
+    __builtin_amdgcn_raw_buffer_store_b128(t.lo, rs, off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(t.hi, rs, off + 16, 0, 16);
+  }
+}
+template <typename V4>
+__device__ __forceinline__ V4 load_word_sc1(__amdgpu_buffer_rsrc_t rs, int off) {
+  if constexpr (sizeof(V4) == 16) {
+    return __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+  } else {
+    u4x2 t;
+    t.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+    t.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16);
+    return __builtin_bit_cast(V4, t);
+  }
+}
+
+// Finish the R rows of a lane (rows lane_row + r*kBlock, valid below row_end) given the segment's sums.
+//   kFinishDirect  apply them.
+//   kFinishStore   store them as this segment's partial; combine_kernel adds the segments later.
+//   kFinishLast    the split-reduction hand-off inside one launch: every workgroup stores its partial with write-through
+//                  stores, every storing wave drains them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane
+//                  takes a ticket with an agent-scope atomic add; the workgroup whose ticket is the last of the row block's
+//                  nseg (over all launches of the step) learns that from the returned value, acquires at agent scope,
+//                  and its lanes read the nseg partials of their rows with sc1 loads IN ASCENDING SEGMENT ORDER — so the
+//                  result is the same whichever workgroup arrives last — then apply them and zero the ticket for the
+//                  next step.  Workgroups of one row block share blockIdx.x; nothing waits on another workgroup.
+//
+// The arguments are re-read here from the kernel-argument segment (every force kernel takes one ForceArgs by value, at
+// offset 0 of it) instead of being kept in SGPRs through the source loop, where the two scalar-load buffers of the
+// delivery need the registers.
+template <typename T, typename V4, int R>
+__device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, const V4 (&me)[R], const Sums<T, R>& s) {
+  const NB_CONST ForceArgs* ka = (const NB_CONST ForceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));   // opaque from here on: the loads below cannot move above the source loop
+  const NB_CONST ForceArgs& a = *ka;
+  if (a.finish == kFinishDirect) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane_row + r * kBlock;
+      if (i < row_end) apply_force<T, V4>(a, i, me[r], s.bx[r], s.by[r], s.bz[r]);
+    }
+    return;
+  }
+  if (a.finish == kFinishStore) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane_row + r * kBlock;
+      V4 o = {s.bx[r], s.by[r], s.bz[r], (T)0};   // S/compute_store.vhd:242 {0, Fz, Fy, Fx}
+      if (i < row_end) ((V4*)a.partial)[(size_t)seg * a.n_rows + i] = o;
+    }
+    return;
+  }
+  __shared__ int s_last;
+  const int wg_row0 = a.row0 + blockIdx.x * (kBlock * R);            // wave-uniform: first row of this workgroup
+  const int wg_rows = min(kBlock * R, row_end - wg_row0);
+  const int lane_off = (int)(threadIdx.x * sizeof(V4));
+  {
+    char* base = (char*)a.partial + ((size_t)seg * a.n_rows + wg_row0) * sizeof(V4);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, wg_rows * (int)sizeof(V4), 0x00020000);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      V4 o = {s.bx[r], s.by[r], s.bz[r], (T)0};
+      store_word_sc1<V4>(rs, lane_off + r * kBlock * (int)sizeof(V4), o);   // rows past row_end fall outside the descriptor: dropped
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(a.tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)(a.nseg - 1));
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  T fx[R], fy[R], fz[R];
+  constexpr int C = R >= 4 ? 2 : (R == 2 ? 4 : 8);   // partials in flight per row (loads first, then the adds in order)
+  for (int sg0 = 0; sg0 < a.nseg; sg0 += C) {
+    V4 p[C][R];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      if (sg0 + k < a.nseg) {
+        char* base = (char*)a.partial + ((size_t)(sg0 + k) * a.n_rows + wg_row0) * sizeof(V4);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, wg_rows * (int)sizeof(V4), 0x00020000);
+#pragma unroll
+        for (int r = 0; r < R; ++r) p[k][r] = load_word_sc1<V4>(rs, lane_off + r * kBlock * (int)sizeof(V4));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      if (sg0 + k < a.nseg) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (sg0 + k == 0) { fx[r] = p[k][r].x; fy[r] = p[k][r].y; fz[r] = p[k][r].z; }
+          else { fx[r] = fx[r] + p[k][r].x; fy[r] = fy[r] + p[k][r].y; fz[r] = fz[r] + p[k][r].z; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = lane_row + r * kBlock;
+    if (i < row_end) apply_force<T, V4>(a, i, me[r], fx[r], fy[r], fz[r]);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(a.tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void block_segment(const ForceArgs& a, int* seg, int* jb, int* je) {
@@ -181,6 +359,18 @@ __device__ __forceinline__ void block_segment(const ForceArgs& a, int* seg, int*
 }
 
 // ---------------------------------------------------------------------------
+// Shared prologue: the R rows of a lane.
+template <typename T, typename V4, int R>
+__device__ __forceinline__ void load_rows(const ForceArgs& a, int lane_row, int row_end, V4 (&me)[R]) {
+  const V4* rows = (const V4*)a.rows;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = lane_row + r * kBlock;
+    me[r] = rows[i < row_end ? i : row_end - 1];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // SMEM variant.  The source words are read with scalar loads (8 bodies = two
 // s_load_dwordx16 per group), land in SGPRs and feed the VALU as scalar
 // operands: no LDS traffic, no barrier, no VALU instruction spent on the
@@ -190,97 +380,99 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const float eps = soft_f32();
-  const f4* rows = (const f4*)a.rows;
   const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
-  float xi[R], yi[R], zi[R], wi[R], ax[R], ay[R], az[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    f4 p = rows[i < row_end ? i : row_end - 1];
-    xi[r] = p.x; yi[r] = p.y; zi[r] = p.z; wi[r] = p.w;
-    ax[r] = ay[r] = az[r] = 0.0f;
-  }
+  f4 me[R];
+  load_rows<float, f4, R>(a, lane_row, row_end, me);
+  Sums<float, R> s;
+  s.clear();
   const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
-  constexpr int G = 8;
-  int j = jb;
-  if (j + G <= je) {
-    f4 cur[G];
+  walk_blocks<float, R>(a, jb, je, s, [&](int j, int j1) {
+    constexpr int G = 8;
+    if (j + G <= j1) {
+      f4 cur[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k) cur[k] = src[j + k];
-    for (; j + 2 * G <= je; j += G) {
-      f4 nxt[G];
+      for (int k = 0; k < G; ++k) cur[k] = src[j + k];
+      for (; j + 2 * G <= j1; j += G) {
+        f4 nxt[G];
 #pragma unroll
-      for (int k = 0; k < G; ++k) nxt[k] = src[j + G + k];
+        for (int k = 0; k < G; ++k) nxt[k] = src[j + G + k];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) pair_f32<ARITH>(cur[k].x, cur[k].y, cur[k].z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) cur[k] = nxt[k];
+      }
 #pragma unroll
       for (int k = 0; k < G; ++k) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) pair_f32<ARITH>(cur[k].x, cur[k].y, cur[k].z, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+        for (int r = 0; r < R; ++r) pair_f32<ARITH>(cur[k].x, cur[k].y, cur[k].z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
       }
-#pragma unroll
-      for (int k = 0; k < G; ++k) cur[k] = nxt[k];
+      j += G;
     }
+    for (; j < j1; ++j) {
+      f4 p = src[j];
 #pragma unroll
-    for (int k = 0; k < G; ++k) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) pair_f32<ARITH>(cur[k].x, cur[k].y, cur[k].z, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+      for (int r = 0; r < R; ++r) pair_f32<ARITH>(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
     }
-    j += G;
-  }
-  for (; j < je; ++j) {
-    f4 p = src[j];
-#pragma unroll
-    for (int r = 0; r < R; ++r) pair_f32<ARITH>(p.x, p.y, p.z, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    if (i < row_end) epilogue_f32(a, seg, i, xi[r], yi[r], zi[r], wi[r], ax[r], ay[r], az[r]);
-  }
+  });
+  finish_rows<float, f4, R>(seg, lane_row, row_end, me, s);
 }
 
 // ---------------------------------------------------------------------------
 // ISA variant (the default for the timed arithmetic): scalar delivery as in force_smem_f32, with the inner loop
 // written instruction by instruction (force_loop_gfx950.inc, generated by tools/gen_force_loop.py, which
-// explains the hardware facts it is built on).  One body per lane; same arithmetic, same order and hence the
-// same bits as force_smem_f32<1, 0>.  PLACEMENT = 1 is the product loop, 0 the same instructions one 4-byte
-// phase off (kept to re-measure the code-placement effect).
+// explains the hardware facts it is built on).  One body per lane; same arithmetic, same order (blocks of
+// sum_block sources folded into the level-2 accumulators inside the loop) and hence the same bits as
+// force_smem_f32<1, 0>.  PLACEMENT = 1 is the product loop, 0 the same instructions one 4-byte phase off (kept to
+// re-measure the code-placement effect).
 #include "force_loop_gfx950.inc"
 template <int PLACEMENT>
 __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const float eps = soft_f32();
-  const f4* rows = (const f4*)a.rows;
   const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
-  const f4 me = rows[i < row_end ? i : row_end - 1];
-  const float xi = me.x, yi = me.y, zi = me.z;
-  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  f4 me[1];
+  load_rows<float, f4, 1>(a, i, row_end, me);
+  const float xi = me[0].x, yi = me[0].y, zi = me[0].z;
+  Sums<float, 1> s;
+  s.clear();
+  float ax = 0.0f, ay = 0.0f, az = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
   int j = jb;
-  const int groups = (je - jb) / NB_FORCE_LOOP_GROUP;
+  const int count = je - jb;
+  const int groups = count / NB_FORCE_LOOP_GROUP;
+  const bool blocked = a.sum_block > 0;
+  // groups per block: sum_block is a multiple of the group (nbody_set_option); sequential = one block never finished
+  const int blk = blocked ? a.sum_block / NB_FORCE_LOOP_GROUP : 0x7fffffff;
   if (groups > 0) {
     const uint64_t p = (uint64_t)(uintptr_t)a.src + (uint64_t)jb * sizeof(f4);
     if constexpr (PLACEMENT == 1) {
       asm volatile(NB_FORCE_LOOP_V1
-                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
-                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
                    : NB_FORCE_LOOP_CLOBBERS);
     } else {
       asm volatile(NB_FORCE_LOOP_V0
-                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
-                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
                    : NB_FORCE_LOOP_CLOBBERS);
     }
     j += groups * NB_FORCE_LOOP_GROUP;
   }
-  // the (< 8) sources left over, with the compiled pair function: identical operations
+  // the (< 8) sources left over, with the compiled pair function: identical operations.  They belong to the last,
+  // unfinished block (sum_block is a multiple of 8, so a block never ends inside them).
   const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
   for (; j < je; ++j) {
     f4 q = src[j];
     pair_f32<0>(q.x, q.y, q.z, xi, yi, zi, eps, ax, ay, az);
   }
-  if (i < row_end) epilogue_f32(a, seg, i, xi, yi, zi, me.w, ax, ay, az);
+  s.ax[0] = ax; s.ay[0] = ay; s.az[0] = az; s.bx[0] = bx; s.by[0] = by; s.bz[0] = bz;
+  s.close(blocked, blocked && (count % a.sum_block) != 0);
+  finish_rows<float, f4, 1>(seg, i, row_end, me, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -288,6 +480,7 @@ __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
 // default).  Double-buffered: the global loads of tile t+1 are issued before
 // the compute on tile t and written to the other buffer after it, one barrier
 // per tile.  Every lane reads the same LDS address: a broadcast, conflict-free.
+// The tile pipeline runs over the whole segment; block ends are found by counting.
 template <int R, int ARITH, int TILE>
 __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
   static_assert(TILE % kBlock == 0, "tile is a multiple of the workgroup");
@@ -296,18 +489,15 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const float eps = soft_f32();
-  const f4* rows = (const f4*)a.rows;
   const f4* src = (const f4*)a.src;
   const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
-  float xi[R], yi[R], zi[R], wi[R], ax[R], ay[R], az[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    f4 p = rows[i < row_end ? i : row_end - 1];
-    xi[r] = p.x; yi[r] = p.y; zi[r] = p.z; wi[r] = p.w;
-    ax[r] = ay[r] = az[r] = 0.0f;
-  }
+  f4 me[R];
+  load_rows<float, f4, R>(a, lane_row, row_end, me);
+  Sums<float, R> s;
+  s.clear();
+  const bool blocked = a.sum_block > 0;
+  int until_fold = blocked ? a.sum_block : 0x7fffffff;   // sources left in the running block
   const int last = a.n_src - 1;
   f4 stage[LPT];
 #pragma unroll
@@ -323,18 +513,26 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
       for (int l = 0; l < LPT; ++l) { int j = nxt0 + l * kBlock + threadIdx.x; stage[l] = src[j < last ? j : last]; }
     }
     const int cnt = je - j0 < TILE ? je - j0 : TILE;
-    if (cnt == TILE) {
+    if (cnt == TILE && until_fold >= TILE) {
 #pragma unroll 8
       for (int k = 0; k < TILE; ++k) {
         f4 p = tile[buf][k];
 #pragma unroll
-        for (int r = 0; r < R; ++r) pair_f32<ARITH>(p.x, p.y, p.z, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+        for (int r = 0; r < R; ++r) pair_f32<ARITH>(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
       }
+      until_fold -= TILE;
+      if (until_fold == 0) { s.fold(); until_fold = a.sum_block; }
     } else {
-      for (int k = 0; k < cnt; ++k) {
-        f4 p = tile[buf][k];
+      int k = 0;
+      while (k < cnt) {
+        const int m = cnt - k < until_fold ? cnt - k : until_fold;
+        for (int e = k + m; k < e; ++k) {
+          f4 p = tile[buf][k];
 #pragma unroll
-        for (int r = 0; r < R; ++r) pair_f32<ARITH>(p.x, p.y, p.z, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+          for (int r = 0; r < R; ++r) pair_f32<ARITH>(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
+        }
+        until_fold -= m;
+        if (until_fold == 0) { s.fold(); until_fold = a.sum_block; }
       }
     }
     if (nxt0 < je) {
@@ -343,11 +541,8 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
     }
     buf ^= 1;
   }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    if (i < row_end) epilogue_f32(a, seg, i, xi[r], yi[r], zi[r], wi[r], ax[r], ay[r], az[r]);
-  }
+  s.close(blocked, blocked && ((je - jb) % a.sum_block) != 0);
+  finish_rows<float, f4, R>(seg, lane_row, row_end, me, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -360,19 +555,16 @@ __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const float eps = soft_f32();
-  const f4* rows = (const f4*)a.rows;
   const f4* src = (const f4*)a.src;
   const int lane = threadIdx.x & 63;
   const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
-  float xi[R], yi[R], zi[R], wi[R], ax[R], ay[R], az[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    f4 p = rows[i < row_end ? i : row_end - 1];
-    xi[r] = p.x; yi[r] = p.y; zi[r] = p.z; wi[r] = p.w;
-    ax[r] = ay[r] = az[r] = 0.0f;
-  }
+  f4 me[R];
+  load_rows<float, f4, R>(a, lane_row, row_end, me);
+  Sums<float, R> s;
+  s.clear();
+  const bool blocked = a.sum_block > 0;
+  int until_fold = blocked ? a.sum_block : 0x7fffffff;
   const int last = a.n_src - 1;
   f4 nxt = src[jb + lane < last ? jb + lane : last];
   for (int j0 = jb; j0 < je; j0 += 64) {
@@ -380,30 +572,30 @@ __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
     int jn = j0 + 64 + lane;
     if (j0 + 64 < je) nxt = src[jn < last ? jn : last];
     const int cnt = je - j0 < 64 ? je - j0 : 64;
-    if (cnt == 64) {
+    if (cnt == 64 && until_fold >= 64) {
 #pragma unroll
       for (int k = 0; k < 64; ++k) {
         float xj = lane_bcast(cur.x, k);
         float yj = lane_bcast(cur.y, k);
         float zj = lane_bcast(cur.z, k);
 #pragma unroll
-        for (int r = 0; r < R; ++r) pair_f32<ARITH>(xj, yj, zj, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+        for (int r = 0; r < R; ++r) pair_f32<ARITH>(xj, yj, zj, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
       }
+      until_fold -= 64;
+      if (until_fold == 0) { s.fold(); until_fold = a.sum_block; }
     } else {
       for (int k = 0; k < cnt; ++k) {
         float xj = lane_bcast(cur.x, k);
         float yj = lane_bcast(cur.y, k);
         float zj = lane_bcast(cur.z, k);
 #pragma unroll
-        for (int r = 0; r < R; ++r) pair_f32<ARITH>(xj, yj, zj, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+        for (int r = 0; r < R; ++r) pair_f32<ARITH>(xj, yj, zj, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
+        if (--until_fold == 0) { s.fold(); until_fold = a.sum_block; }
       }
     }
   }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    if (i < row_end) epilogue_f32(a, seg, i, xi[r], yi[r], zi[r], wi[r], ax[r], ay[r], az[r]);
-  }
+  s.close(blocked, blocked && ((je - jb) % a.sum_block) != 0);
+  finish_rows<float, f4, R>(seg, lane_row, row_end, me, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -417,10 +609,10 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const float eps = soft_f32();
-  const f4* rows = (const f4*)a.rows;
   const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
-  f4 me = rows[i < row_end ? i : row_end - 1];
+  f4 me[1];
+  load_rows<float, f4, 1>(a, i, row_end, me);
   float px[16], py[16], pz[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) px[k] = py[k] = pz[k] = 0.0f;
@@ -430,7 +622,7 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       f4 p = src[j + k];
-      pair_f32<ARITH>(p.x, p.y, p.z, me.x, me.y, me.z, eps, px[k], py[k], pz[k]);
+      pair_f32<ARITH>(p.x, p.y, p.z, me[0].x, me[0].y, me[0].z, eps, px[k], py[k], pz[k]);
     }
   }
   const int tail = je - j;   // < 16
@@ -438,7 +630,7 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
   for (int k = 0; k < 16; ++k) {
     if (k < tail) {
       f4 p = src[j + k];
-      pair_f32<ARITH>(p.x, p.y, p.z, me.x, me.y, me.z, eps, px[k], py[k], pz[k]);
+      pair_f32<ARITH>(p.x, p.y, p.z, me[0].x, me[0].y, me[0].z, eps, px[k], py[k], pz[k]);
     }
   }
   // results(t) = partial[(count + t) mod 16], zero where no item existed
@@ -455,28 +647,26 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
     if (count - 16 + t < 0) { vx = vy = vz = 0.f; }
     rx[t] = vx; ry[t] = vy; rz[t] = vz;
   }
-  float fx = tree16(rx), fy = tree16(ry), fz = tree16(rz);
-  if (i < row_end) epilogue_f32(a, seg, i, me.x, me.y, me.z, me.w, fx, fy, fz);
+  Sums<float, 1> s;
+  s.clear();
+  s.bx[0] = tree16(rx); s.by[0] = tree16(ry); s.bz[0] = tree16(rz);
+  finish_rows<float, f4, 1>(seg, i, row_end, me, s);
 }
 
 // ---------------------------------------------------------------------------
-// fp64 (BASELINE config 5).  SMEM delivery, R bodies per lane.
+// fp64 (BASELINE config 5).  SMEM delivery, R bodies per lane.  One sequential sum per segment (fp64 has 29 more
+// bits than the 1e-5 target needs; sum_block is ignored).
 template <int R>
 __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const double eps = (double)soft_f32();
-  const d4* rows = (const d4*)a.rows;
   const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
-  double xi[R], yi[R], zi[R], wi[R], ax[R], ay[R], az[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    d4 p = rows[i < row_end ? i : row_end - 1];
-    xi[r] = p.x; yi[r] = p.y; zi[r] = p.z; wi[r] = p.w;
-    ax[r] = ay[r] = az[r] = 0.0;
-  }
+  d4 me[R];
+  load_rows<double, d4, R>(a, lane_row, row_end, me);
+  Sums<double, R> s;
+  s.clear();
   const NB_CONST d4* src = (const NB_CONST d4*)(uintptr_t)a.src;
   constexpr int G = 4;
   int j = jb;
@@ -487,37 +677,16 @@ __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
 #pragma unroll
     for (int k = 0; k < G; ++k) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) pair_f64(cur[k].x, cur[k].y, cur[k].z, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+      for (int r = 0; r < R; ++r) pair_f64(cur[k].x, cur[k].y, cur[k].z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
     }
   }
   for (; j < je; ++j) {
     d4 p = src[j];
 #pragma unroll
-    for (int r = 0; r < R; ++r) pair_f64(p.x, p.y, p.z, xi[r], yi[r], zi[r], eps, ax[r], ay[r], az[r]);
+    for (int r = 0; r < R; ++r) pair_f64(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
   }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int i = lane_row + r * kBlock;
-    if (i >= row_end) continue;
-    if (a.fused) {
-      d4* vel = (d4*)a.vel;
-      d4* pn = (d4*)a.pos_next_rows;
-      d4 v = vel[i];
-      v.x = __builtin_fma(a.dt64, ax[r], v.x);
-      v.y = __builtin_fma(a.dt64, ay[r], v.y);
-      v.z = __builtin_fma(a.dt64, az[r], v.z);
-      vel[i] = v;
-      d4 p;
-      p.x = __builtin_fma(v.x, a.dt64, xi[r]);
-      p.y = __builtin_fma(v.y, a.dt64, yi[r]);
-      p.z = __builtin_fma(v.z, a.dt64, zi[r]);
-      p.w = wi[r];
-      pn[i] = p;
-    } else {
-      d4 o = {ax[r], ay[r], az[r], 0.0};
-      ((d4*)a.partial)[(size_t)seg * a.n_rows + i] = o;
-    }
-  }
+  s.close(false, false);
+  finish_rows<double, d4, R>(seg, lane_row, row_end, me, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -528,11 +697,11 @@ __global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const double eps = (double)soft_f32();
-  const d4* rows = (const d4*)a.rows;
   const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
-  const d4 me = rows[i < row_end ? i : row_end - 1];
-  const double xi = me.x, yi = me.y, zi = me.z;
+  d4 me[1];
+  load_rows<double, d4, 1>(a, i, row_end, me);
+  const double xi = me[0].x, yi = me[0].y, zi = me[0].z;
   double ax = 0.0, ay = 0.0, az = 0.0;
   int j = jb;
   const int groups = (je - jb) / NB_FORCE_LOOP_F64_GROUP;
@@ -556,76 +725,28 @@ __global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
     d4 q = src[j];
     pair_f64(q.x, q.y, q.z, xi, yi, zi, eps, ax, ay, az);
   }
-  if (i < row_end) {
-    if (a.fused) {
-      d4* vel = (d4*)a.vel;
-      d4* pn = (d4*)a.pos_next_rows;
-      d4 v = vel[i];
-      v.x = __builtin_fma(a.dt64, ax, v.x);
-      v.y = __builtin_fma(a.dt64, ay, v.y);
-      v.z = __builtin_fma(a.dt64, az, v.z);
-      vel[i] = v;
-      d4 q;
-      q.x = __builtin_fma(v.x, a.dt64, xi);
-      q.y = __builtin_fma(v.y, a.dt64, yi);
-      q.z = __builtin_fma(v.z, a.dt64, zi);
-      q.w = me.w;
-      pn[i] = q;
-    } else {
-      d4 o = {ax, ay, az, 0.0};
-      ((d4*)a.partial)[(size_t)seg * a.n_rows + i] = o;
-    }
-  }
+  Sums<double, 1> s;
+  s.clear();
+  s.bx[0] = ax; s.by[0] = ay; s.bz[0] = az;
+  finish_rows<double, d4, 1>(seg, i, row_end, me, s);
 }
 
 // ---------------------------------------------------------------------------
-// combine: F_i = ((p_0 + p_1) + p_2) + ... over the segments in ascending source
-// order (so the result does not depend on the order in which slices arrived),
-// then kick and/or drift.  HBM-bound, nseg x 16 B per body.
-struct CombineArgs {
-  const void* partial;   // [nseg][n_rows]
-  const void* pos_rows;  // current positions of the rank's bodies
-  void* pos_next_rows;   // may alias nothing in pos_rows' buffer
-  void* vel;
-  void* force_out;       // nullable
-  int nseg, n_rows, row0, row_count;
-  int do_kick, do_drift;
-  float dt;
-  double dt64;
-};
-
+// combine (the two-launch form of a step, NBODY_OPT_FUSE_COMBINE = 0): F_i = ((p_0 + p_1) + p_2) + ... over the
+// segments in ascending source order (so the result does not depend on the order in which slices arrived), then
+// what apply_force does.  HBM-bound, nseg x 16 B per body.  Same operations as the last-arriver path of finish_rows.
 template <typename T, typename V4>
-__global__ void __launch_bounds__(kBlock) combine_kernel(CombineArgs a) {
-  int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
+__global__ void __launch_bounds__(kBlock) combine_kernel(ForceArgs a) {
+  const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.row0 + a.row_count) return;
   const V4* part = (const V4*)a.partial;
   V4 f = part[i];
-  for (int s = 1; s < a.nseg; ++s) {
-    V4 p = part[(size_t)s * a.n_rows + i];
+  for (int sg = 1; sg < a.nseg; ++sg) {
+    V4 p = part[(size_t)sg * a.n_rows + i];
     f.x = f.x + p.x; f.y = f.y + p.y; f.z = f.z + p.z;
   }
-  f.w = (T)0;
-  if (a.force_out) ((V4*)a.force_out)[i] = f;
-  const T dt = sizeof(T) == 8 ? (T)a.dt64 : (T)a.dt;
-  if (a.do_kick) {
-    V4* vel = (V4*)a.vel;
-    V4 v = vel[i];
-    if constexpr (sizeof(T) == 8) {
-      v.x = __builtin_fma(dt, f.x, v.x); v.y = __builtin_fma(dt, f.y, v.y); v.z = __builtin_fma(dt, f.z, v.z);
-    } else {
-      v.x = __builtin_fmaf(dt, f.x, v.x); v.y = __builtin_fmaf(dt, f.y, v.y); v.z = __builtin_fmaf(dt, f.z, v.z);
-    }
-    vel[i] = v;
-    if (a.do_drift) {
-      V4 p = ((const V4*)a.pos_rows)[i];
-      if constexpr (sizeof(T) == 8) {
-        p.x = __builtin_fma(v.x, dt, p.x); p.y = __builtin_fma(v.y, dt, p.y); p.z = __builtin_fma(v.z, dt, p.z);
-      } else {
-        p.x = __builtin_fmaf(v.x, dt, p.x); p.y = __builtin_fmaf(v.y, dt, p.y); p.z = __builtin_fmaf(v.z, dt, p.z);
-      }
-      ((V4*)a.pos_next_rows)[i] = p;
-    }
-  }
+  const V4 me = ((const V4*)a.rows)[i];
+  apply_force<T, V4>(a, i, me, f.x, f.y, f.z);
 }
 
 // integrate(): r += v * dt for the rank's bodies, in place.
@@ -636,11 +757,7 @@ __global__ void __launch_bounds__(kBlock) drift_kernel(V4* pos_rows, const V4* v
   const T dt = sizeof(T) == 8 ? (T)dt64 : (T)dt32;
   V4 p = pos_rows[i];
   V4 v = vel[i];
-  if constexpr (sizeof(T) == 8) {
-    p.x = __builtin_fma(v.x, dt, p.x); p.y = __builtin_fma(v.y, dt, p.y); p.z = __builtin_fma(v.z, dt, p.z);
-  } else {
-    p.x = __builtin_fmaf(v.x, dt, p.x); p.y = __builtin_fmaf(v.y, dt, p.y); p.z = __builtin_fmaf(v.z, dt, p.z);
-  }
+  p.x = fma_t(v.x, dt, p.x); p.y = fma_t(v.y, dt, p.y); p.z = fma_t(v.z, dt, p.z);
   pos_rows[i] = p;
 }
 

@@ -43,8 +43,11 @@ class NBody:
     @property
     def config(self):
         names = {L.VARIANT_SMEM: "smem", L.VARIANT_LDS: "lds", L.VARIANT_READLANE: "readlane", L.VARIANT_ISA: "isa"}
+        sums = {L.SUM_SEQ: "seq", L.SUM_FPGA16: "fpga16", L.SUM_BLOCKED: "blocked"}
         return dict(variant=names.get(self.info(L.INFO_VARIANT), "?"), iblock=self.info(L.INFO_IBLOCK),
                     jsub=self.info(L.INFO_JSUB), nseg=self.info(L.INFO_NSEG), tile=self.info(L.INFO_TILE),
+                    sum_order=sums.get(self.info(L.INFO_SUM_ORDER), "?"), sum_block=self.info(L.INFO_SUM_BLOCK),
+                    launches_per_step=self.info(L.INFO_LAUNCHES_PER_STEP),
                     n_local=self.info(L.INFO_N_LOCAL), first_body=self.info(L.INFO_FIRST_BODY),
                     rank=self.info(L.INFO_RANK), nranks=self.info(L.INFO_NRANKS))
 
@@ -114,10 +117,29 @@ class NBody:
         return out
 
     def forces_rows(self, first_row, n_rows):
-        """Forces on a row sample from the state on the device (fp32, one GPU)."""
-        out = np.empty((n_rows, 4), np.float32)
-        L.check(self.lib.nbody_forces_rows(int(first_row), int(n_rows), out.ctypes.data_as(C.POINTER(C.c_float))))
+        """Forces on a row sample (rows of this rank's slice) from the state on the device."""
+        out = np.empty((n_rows, 4), self.dtype)
+        if self.fp64:
+            L.check(self.lib.nbody_forces_rows_d(int(first_row), int(n_rows), out.ctypes.data_as(C.POINTER(C.c_double))))
+        else:
+            L.check(self.lib.nbody_forces_rows(int(first_row), int(n_rows), out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def comm_selftest(self):
+        """Push a patterned array through the RCCL calls of the multi-GPU path (all-gather + one ring step); returns
+        the bytes this rank received.  Needs the communicator of NBody(..., rank=, nranks=, uid=)."""
+        moved = C.c_longlong()
+        L.check(self.lib.nbody_comm_selftest(C.byref(moved)))
+        return moved.value
+
+    @property
+    def order(self):
+        """The summation order of the current configuration as keyword arguments of the oracle's order()
+        (tests mirror the engine's order with it)."""
+        cfg = self.config
+        nsl = cfg["nseg"] // cfg["jsub"]
+        return dict(nslices=nsl, sub=cfg["jsub"], block=cfg["sum_block"] or 1024,
+                    summ={"seq": 0, "fpga16": 1, "blocked": 2}[cfg["sum_order"]])
 
     def kernel_time(self, reset=False):
         ms, cnt = C.c_double(), C.c_longlong()

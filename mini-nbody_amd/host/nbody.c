@@ -7,6 +7,7 @@
  * §2: billion pair-interactions/s = N^2 * timed_steps / seconds / 1e9.
  *
  * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]
+ *              [--sum seq|blocked] [--block K] [--two-launch]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -26,7 +27,7 @@ static double now_s(void) {
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s failed: %s\n", #call, nbody_error_string(rc_)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0;
+  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0, sum = -1, block = 0, two_launch = 0;
   unsigned long long seed = NBODY_IC_DEFAULT_SEED;
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
@@ -36,9 +37,12 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--fp64")) fp64 = 1;
     else if (!strcmp(argv[a], "--host-loop")) host_loop = 1;
     else if (!strcmp(argv[a], "--strict")) strict = 1;
+    else if (!strcmp(argv[a], "--two-launch")) two_launch = 1;
+    else if (!strcmp(argv[a], "--sum") && a + 1 < argc) { ++a; sum = !strcmp(argv[a], "seq") ? NBODY_SUM_SEQ : NBODY_SUM_BLOCKED; }
+    else if (!strcmp(argv[a], "--block") && a + 1 < argc) block = atoi(argv[++a]);
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--two-launch]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   const float dt = 0.01f;
@@ -46,6 +50,9 @@ int main(int argc, char **argv) {
   CHECK(nbody_init(n, gpus, fp64, tile));
   if (strict) CHECK(nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_STRICT));   /* IEEE-exact: bit-identical to the CPU oracle */
   if (jsub > 0) CHECK(nbody_set_option(NBODY_OPT_JSUB, jsub));                 /* source segments (summation order) */
+  if (sum >= 0) CHECK(nbody_set_option(NBODY_OPT_SUM_ORDER, sum));             /* one sequential sum per segment, or blocks */
+  if (block > 0) CHECK(nbody_set_option(NBODY_OPT_SUM_BLOCK, block));
+  if (two_launch) CHECK(nbody_set_option(NBODY_OPT_FUSE_COMBINE, 0));          /* separate combine kernel (same bits) */
 
   double total = 0.0;
   if (!fp64) {
@@ -104,12 +111,14 @@ int main(int argc, char **argv) {
     free(buf);
   }
   double avg = total / (double)(iters - 1);
-  long long info_r = 0, info_s = 0;
+  long long info_r = 0, info_s = 0, info_b = 0, info_l = 0;
   nbody_get_info(NBODY_INFO_IBLOCK, &info_r);
   nbody_get_info(NBODY_INFO_NSEG, &info_s);
-  printf("%d Bodies (%s, %d GPU%s, %s loop, %lld bodies/lane, %lld segments): average %0.3f Billion Interactions / second (%.3f ms / step)\n",
-         n, fp64 ? "fp64" : "fp32", gpus, gpus > 1 ? "s" : "", host_loop ? "host" : "device", info_r, info_s,
-         1e-9 * (double)n * (double)n / avg, 1e3 * avg);
+  nbody_get_info(NBODY_INFO_SUM_BLOCK, &info_b);
+  nbody_get_info(NBODY_INFO_LAUNCHES_PER_STEP, &info_l);
+  printf("%d Bodies (%s, %d GPU%s, %s loop, %lld bodies/lane, %lld segments, sum block %lld, %lld launch%s/step): average %0.3f Billion Interactions / second (%.3f ms / step)\n",
+         n, fp64 ? "fp64" : "fp32", gpus, gpus > 1 ? "s" : "", host_loop ? "host" : "device", info_r, info_s, info_b, info_l,
+         info_l > 1 ? "es" : "", 1e-9 * (double)n * (double)n / avg, 1e3 * avg);
   nbody_shutdown();
   return 0;
 }

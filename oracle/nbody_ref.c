@@ -190,12 +190,106 @@ void ref_forces_f32(const float *rows, int n_rows, const float *src, int n_src, 
                     int d2_mode, int rsqrt_mode, int sum_mode) {
   if (n_rows <= 0) return;
   if (sum_mode == REF_SUM_FPGA16) { fpga16_f32(rows, n_rows, src, n_src, acc, d2_mode, rsqrt_mode); return; }
+  if (sum_mode == REF_SUM_BLOCKED) {   /* one segment, blocks of 1024 (the engine's default block) */
+    ref_order_t o = {d2_mode, rsqrt_mode, REF_SUM_BLOCKED, 1024, 1, 1};
+    ref_forces_f32_order(rows, n_rows, src, n_src, acc, &o);
+    return;
+  }
   if (d2_mode == REF_D2_REFERENCE) {
     if (rsqrt_mode == REF_RSQRT_DIVSQRT) seq_ref_div(rows, n_rows, src, n_src, acc_in, acc);
     else seq_ref_f64(rows, n_rows, src, n_src, acc_in, acc);
   } else {
     if (rsqrt_mode == REF_RSQRT_DIVSQRT) seq_fma_div(rows, n_rows, src, n_src, acc_in, acc);
     else seq_fma_f64(rows, n_rows, src, n_src, acc_in, acc);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* The engine's summation order (ref_order_t in nbody_ref.h).
+ * Slices and pieces as mini-nbody_amd/csrc/nbody_kernels.hpp slice_first()/segment_bounds(): slice q of P is balanced
+ * (the first n % P slices have one body more); a slice is cut into `sub` pieces of ceil(len / sub) sources. */
+static int slice_first_(int q, int n, int P) {
+  int base = n / P, rem = n % P;
+  return q * base + (q < rem ? q : rem);
+}
+void ref_segment_bounds(int q, int t, int n, int nslices, int sub, int *jb, int *je) {
+  int f0 = slice_first_(q, n, nslices), f1 = slice_first_(q + 1, n, nslices);
+  int len = f1 - f0;
+  int piece = (len + sub - 1) / sub;
+  int b = f0 + t * piece;
+  int e = b + piece;
+  if (b > f1) b = f1;
+  if (e > f1) e = f1;
+  *jb = b; *je = e;
+}
+
+/* Per row: for every segment in ascending order { level 1: a = 0, a = fma(d, inv3, a) over a block of sources
+ * (S/fxyz.vhd:120-127); level 2: b = b + a per finished block }, then F = p_0, F = F + p_s.  In REF_SUM_SEQ a segment is
+ * one block and its sum is `a` itself (no addition of zero).  Rows are processed LANES at a time for the vectoriser;
+ * the order of operations per row is exactly the one written here. */
+#define DEFINE_ORDER_KERNEL(NAME, D2MODE, RSQMODE)                                                       \
+  static void NAME(const float *rows, int n_rows, const float *src, int n_src, float *acc,               \
+                   int blocked, int block, int nslices, int sub) {                                       \
+    const float soft = bits_to_float(REF_SOFT_BITS);                                                     \
+    const int nblk = (n_rows + LANES - 1) / LANES;                                                       \
+    _Pragma("omp parallel for schedule(dynamic, 4)")                                                     \
+    for (int b = 0; b < nblk; ++b) {                                                                     \
+      float xs[LANES], ys[LANES], zs[LANES], tx[LANES], ty[LANES], tz[LANES];                            \
+      for (int l = 0; l < LANES; ++l) {                                                                  \
+        int i = b * LANES + l; if (i >= n_rows) i = n_rows - 1;                                          \
+        xs[l] = rows[4 * i]; ys[l] = rows[4 * i + 1]; zs[l] = rows[4 * i + 2];                           \
+        tx[l] = ty[l] = tz[l] = 0.0f;                                                                    \
+      }                                                                                                  \
+      for (int seg = 0; seg < nslices * sub; ++seg) {                                                    \
+        int jb, je;                                                                                      \
+        ref_segment_bounds(seg / sub, seg % sub, n_src, nslices, sub, &jb, &je);                         \
+        float px[LANES], py[LANES], pz[LANES];                                                           \
+        for (int l = 0; l < LANES; ++l) px[l] = py[l] = pz[l] = 0.0f;                                    \
+        const int step = blocked ? block : (je - jb > 0 ? je - jb : 1);                                  \
+        for (int j0 = jb; j0 < je; j0 += step) {                                                         \
+          const int j1 = j0 + step < je ? j0 + step : je;                                                \
+          float fx[LANES], fy[LANES], fz[LANES];                                                         \
+          for (int l = 0; l < LANES; ++l) fx[l] = fy[l] = fz[l] = 0.0f;                                  \
+          for (int j = j0; j < j1; ++j) {                                                                \
+            const float xt = src[4 * j], yt = src[4 * j + 1], zt = src[4 * j + 2];                       \
+            _Pragma("omp simd")                                                                          \
+            for (int l = 0; l < LANES; ++l) {                                                            \
+              const float xi = xs[l], yi = ys[l], zi = zs[l];                                            \
+              PAIR_F32(D2MODE, RSQMODE)                                                                  \
+              fx[l] = fmaf(dx, inv3, fx[l]);                                                             \
+              fy[l] = fmaf(dy, inv3, fy[l]);                                                             \
+              fz[l] = fmaf(dz, inv3, fz[l]);                                                             \
+            }                                                                                            \
+          }                                                                                              \
+          if (blocked) { for (int l = 0; l < LANES; ++l) { px[l] = px[l] + fx[l]; py[l] = py[l] + fy[l]; pz[l] = pz[l] + fz[l]; } } \
+          else { for (int l = 0; l < LANES; ++l) { px[l] = fx[l]; py[l] = fy[l]; pz[l] = fz[l]; } }      \
+        }                                                                                                \
+        if (seg == 0) { for (int l = 0; l < LANES; ++l) { tx[l] = px[l]; ty[l] = py[l]; tz[l] = pz[l]; } } \
+        else { for (int l = 0; l < LANES; ++l) { tx[l] = tx[l] + px[l]; ty[l] = ty[l] + py[l]; tz[l] = tz[l] + pz[l]; } } \
+      }                                                                                                  \
+      for (int l = 0; l < LANES; ++l) {                                                                  \
+        int i = b * LANES + l; if (i >= n_rows) break;                                                   \
+        acc[4 * i] = tx[l]; acc[4 * i + 1] = ty[l]; acc[4 * i + 2] = tz[l]; acc[4 * i + 3] = 0.0f;       \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+DEFINE_ORDER_KERNEL(ord_ref_f64, REF_D2_REFERENCE, REF_RSQRT_F64)
+DEFINE_ORDER_KERNEL(ord_ref_div, REF_D2_REFERENCE, REF_RSQRT_DIVSQRT)
+DEFINE_ORDER_KERNEL(ord_fma_f64, REF_D2_FMA3, REF_RSQRT_F64)
+DEFINE_ORDER_KERNEL(ord_fma_div, REF_D2_FMA3, REF_RSQRT_DIVSQRT)
+
+void ref_forces_f32_order(const float *rows, int n_rows, const float *src, int n_src, float *acc, const ref_order_t *o) {
+  if (n_rows <= 0) return;
+  const int blocked = o->sum_mode == REF_SUM_BLOCKED;
+  const int block = o->block > 0 ? o->block : 1024;
+  const int nsl = o->nslices > 0 ? o->nslices : 1, sub = o->sub > 0 ? o->sub : 1;
+  if (o->d2_mode == REF_D2_REFERENCE) {
+    if (o->rsqrt_mode == REF_RSQRT_DIVSQRT) ord_ref_div(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
+    else ord_ref_f64(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
+  } else {
+    if (o->rsqrt_mode == REF_RSQRT_DIVSQRT) ord_fma_div(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
+    else ord_fma_f64(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
   }
 }
 
@@ -265,6 +359,16 @@ void ref_step_f32(float *pos, float *vel, float dt, int n, int nsteps, int d2_mo
     ref_bodyForce_f32(pos, vel, dt, n, d2_mode, rsqrt_mode, sum_mode);
     ref_integrate_f32(pos, vel, dt, n);
   }
+}
+void ref_step_f32_order(float *pos, float *vel, float dt, int n, int nsteps, const ref_order_t *order) {
+  float *acc = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+  for (int s = 0; s < nsteps; ++s) {
+    ref_forces_f32_order(pos, n, pos, n, acc, order);
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < 3; ++c) vel[4 * i + c] = fmaf(dt, acc[4 * i + c], vel[4 * i + c]);
+    ref_integrate_f32(pos, vel, dt, n);
+  }
+  free(acc);
 }
 void ref_step_f64(double *pos, double *vel, double dt, int n, int nsteps) {
   for (int s = 0; s < nsteps; ++s) {

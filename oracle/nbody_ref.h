@@ -40,7 +40,23 @@ enum { REF_RSQRT_F64 = 0,     /* (float)(1.0/sqrt((double)d2)): one rounding fro
        REF_RSQRT_DIVSQRT = 1  /* 1.0f/sqrtf(d2): two fp32 roundings (what a plain C nbody does) */ };
 /* in which order the per-source terms are summed */
 enum { REF_SUM_SEQ = 0,      /* one accumulator, sources in ascending order (S/top_level.vhd:233-254) */
-       REF_SUM_FPGA16 = 1    /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */ };
+       REF_SUM_FPGA16 = 1,   /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */
+       REF_SUM_BLOCKED = 2   /* two levels: blocks of `block` consecutive sources are summed sequentially from zero and the
+                                block sums are added, in ascending order, into a second accumulator.  The reference never
+                                runs one long sequential sum either: it keeps 16 partial sums and adds them with a tree
+                                (S/fxyz.vhd:129-145, S/final_adder.vhd:88-104); this is the same remedy shaped for a SIMT
+                                lane (one fold per `block` sources instead of 16 live partials) */ };
+
+/* The engine's full summation order (mini-nbody_amd/csrc/nbody_kernels.hpp): the sources are cut into `nslices` balanced
+ * slices (one per rank) of `sub` pieces each; every segment is summed on its own from zero (sum_mode, `block` sources per
+ * block when sum_mode == REF_SUM_BLOCKED, counted from the segment's first source), and the segment sums are added in
+ * ascending source order: F = ((p_0 + p_1) + p_2) + ...  nslices = sub = 1 and REF_SUM_SEQ is the plain sequential sum. */
+typedef struct {
+  int d2_mode, rsqrt_mode;
+  int sum_mode;      /* REF_SUM_SEQ or REF_SUM_BLOCKED */
+  int block;         /* sources per block (REF_SUM_BLOCKED) */
+  int nslices, sub;  /* segmentation of the sources */
+} ref_order_t;
 
 /* ---- pipeline stages, one function per reference entity ---- */
 float ref_soft(void);
@@ -67,6 +83,10 @@ float ref_tree16(const float p[16]);
  * acc_in (may be NULL): starting value of the accumulators (sequential mode only) */
 void ref_forces_f32(const float *rows, int n_rows, const float *src, int n_src, const float *acc_in, float *acc,
                     int d2_mode, int rsqrt_mode, int sum_mode);
+/* forces in the engine's order (segments, blocks): rows vs ALL n_src sources */
+void ref_forces_f32_order(const float *rows, int n_rows, const float *src, int n_src, float *acc, const ref_order_t *order);
+/* segment (q, t) of the order: [*jb, *je) */
+void ref_segment_bounds(int q, int t, int n, int nslices, int sub, int *jb, int *je);
 /* fp64 arithmetic on fp64 inputs (the fp64 config's oracle) */
 void ref_forces_f64(const double *rows, int n_rows, const double *src, int n_src, double *acc);
 /* fp64 arithmetic on fp32 inputs, fp64 outputs: the arbiter between fp32 orders */
@@ -81,6 +101,8 @@ void ref_integrate_f64(double *pos, const double *vel, double dt, int n);
 /* nsteps x { bodyForce; integrate } */
 void ref_step_f32(float *pos, float *vel, float dt, int n, int nsteps, int d2_mode, int rsqrt_mode, int sum_mode);
 void ref_step_f64(double *pos, double *vel, double dt, int n, int nsteps);
+/* the same loop with the forces summed in the engine's order */
+void ref_step_f32_order(float *pos, float *vel, float dt, int n, int nsteps, const ref_order_t *order);
 
 /* deterministic initial conditions (include/nbody_ic.h) */
 void ref_ic_f32(float *pos, float *vel, int n, int first, int count, uint64_t seed);

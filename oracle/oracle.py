@@ -13,11 +13,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 D2_REFERENCE, D2_FMA3 = 0, 1
 RSQRT_F64, RSQRT_DIVSQRT = 0, 1
-SUM_SEQ, SUM_FPGA16 = 0, 1
+SUM_SEQ, SUM_FPGA16, SUM_BLOCKED = 0, 1, 2
+DEFAULT_BLOCK = 1024
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _fp = C.POINTER(C.c_float)
+
+
+class Order(C.Structure):
+    """ref_order_t: the engine's summation order (segments of the sources, blocks inside a segment)."""
+    _fields_ = [("d2_mode", C.c_int), ("rsqrt_mode", C.c_int), ("sum_mode", C.c_int), ("block", C.c_int),
+                ("nslices", C.c_int), ("sub", C.c_int)]
+
+
+def order(d2=D2_FMA3, rsqrt=RSQRT_F64, summ=SUM_BLOCKED, block=DEFAULT_BLOCK, nslices=1, sub=1):
+    return Order(d2, rsqrt, summ, block, nslices, sub)
 
 
 def build(force=False):
@@ -58,6 +69,9 @@ class Oracle:
         L.ref_integrate_f64.argtypes = [_f64p, _f64p, C.c_double, C.c_int]
         L.ref_step_f32.argtypes = [_f32p, _f32p, f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_step_f64.argtypes = [_f64p, _f64p, C.c_double, C.c_int, C.c_int]
+        L.ref_forces_f32_order.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _f32p, C.POINTER(Order)]
+        L.ref_step_f32_order.argtypes = [_f32p, _f32p, f, C.c_int, C.c_int, C.POINTER(Order)]
+        L.ref_segment_bounds.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 2
         L.ref_ic_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_uint64]
         L.ref_ic_f64.argtypes = [_f64p, _f64p, C.c_int, C.c_int, C.c_int, C.c_uint64]
         L.ref_num_threads.restype = C.c_int
@@ -107,6 +121,24 @@ class Oracle:
             ptr = None
         self.lib.ref_forces_f32(rows, len(rows), src, len(src), ptr, acc, d2, rsqrt, summ)
         return acc
+
+    def forces_order(self, rows, src=None, order_=None, **kw):
+        """Forces in the engine's summation order: order_ = oracle.order(...) or keyword arguments of it."""
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 4)
+        src = rows if src is None else np.ascontiguousarray(src, np.float32).reshape(-1, 4)
+        o = order_ if order_ is not None else order(**kw)
+        acc = np.zeros_like(rows)
+        self.lib.ref_forces_f32_order(rows, len(rows), src, len(src), acc, C.byref(o))
+        return acc
+
+    def step_order(self, pos, vel, dt, nsteps, order_=None, **kw):
+        o = order_ if order_ is not None else order(**kw)
+        self.lib.ref_step_f32_order(pos, vel, dt, len(pos), nsteps, C.byref(o))
+
+    def segment_bounds(self, q, t, n, nslices, sub):
+        b, e = C.c_int(), C.c_int()
+        self.lib.ref_segment_bounds(q, t, n, nslices, sub, C.byref(b), C.byref(e))
+        return b.value, e.value
 
     def forces_f64(self, rows, src=None):
         rows = np.ascontiguousarray(rows, np.float64).reshape(-1, 4)

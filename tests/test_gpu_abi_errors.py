@@ -30,6 +30,11 @@ def test_error_codes_and_recovery(nb):
         assert lib.nbody_step_d(0.01, 1) == L.ERR_STATE            # fp64 call on an fp32 context
         assert lib.bodyForce_d(None, None, 0.01, 128) == L.ERR_STATE
         assert lib.nbody_forces_rows(0, 129, p) == L.ERR_ARG
+        assert lib.nbody_forces_rows_d(0, 1, buf.ctypes.data_as(C.POINTER(C.c_double))) == L.ERR_STATE   # fp64 call, fp32 context
+        assert lib.nbody_comm_selftest(None) == L.ERR_STATE        # not a multi-process context: no communicator
+        assert lib.nbody_set_option(nb.OPT_SUM_BLOCK, 100) == L.ERR_ARG   # not a multiple of 64
+        assert lib.nbody_set_option(nb.OPT_SUM_ORDER, 3) == L.ERR_ARG
+        assert lib.nbody_set_option(nb.OPT_OVERLAP, 3) == L.ERR_ARG
         assert lib.nbody_set_option(nb.OPT_VARIANT, 99) == L.ERR_ARG
         ram_a = np.zeros((129, 4), np.uint32)                      # BEGIN not set
         assert lib.nbody_mailbox_run(ram_a.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), 0) == L.ERR_STATE

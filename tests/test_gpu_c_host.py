@@ -17,27 +17,35 @@ EXE = os.path.join(ROOT, "build", "nbody")
 def test_c_host_program_matches_oracle(nb, oracle_fast, extra):
     if not os.path.exists(EXE):
         pytest.fail("build/nbody is missing: run `make host`")
+    import oracle as O
     n, iters = 4096, 10
-    env = dict(os.environ, NBODY_JSUB="1")
-    out = subprocess.run([EXE, str(n), str(iters), "--strict", "--jsub", "1"] + extra, capture_output=True, text=True, env=env, timeout=300)
+    out = subprocess.run([EXE, str(n), str(iters), "--strict"] + extra, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"checksum \(sum of positions\): (\S+) (\S+) (\S+)", out.stdout)
     assert m, out.stdout
     got = np.array([float(m.group(k)) for k in (1, 2, 3)])
+    cfg = re.search(r"(\d+) segments, sum block (\d+), (\d+) launch", out.stdout)
+    assert cfg, out.stdout
+    segments, block, launches = (int(cfg.group(k)) for k in (1, 2, 3))
+    assert block == 1024 and launches == 1 and segments > 1      # the engine's own configuration
     pos, vel = nb.make_bodies(n)
-    oracle_fast.step(pos, vel, 0.01, iters)
+    oracle_fast.step_order(pos, vel, 0.01, iters, summ=O.SUM_BLOCKED, block=block, sub=segments)
     want = pos[:, :3].astype(np.float64).sum(0)
     assert np.allclose(got, want, rtol=0, atol=1e-6 * np.abs(pos[:, :3]).sum()), (got, want)   # printed with %.9g
     assert re.search(r"%d Bodies .* Billion Interactions / second" % n, out.stdout)
 
 
 def test_gpu_host_program_and_cpu_program_print_the_same_checksum():
-    """BASELINE config 1 (CPU program, oracle/nbody_cpu) next to the GPU host program in --strict mode, one source
-    segment: identical initial conditions, identical arithmetic, identical checksum line."""
+    """BASELINE config 1 (CPU program, oracle/nbody_cpu) next to the GPU host program in --strict mode: identical
+    initial conditions, identical arithmetic, identical checksum line — with one sequential sum per body (what a plain
+    CPU nbody.c does) and in the engine's default order (blocked sums, 16 source segments at this size, one launch/step)."""
     cpu = os.path.join(ROOT, "oracle", "nbody_cpu")
     assert os.path.exists(cpu) and os.path.exists(EXE)
-    a = subprocess.run([cpu, "4096", "10"], capture_output=True, text=True, timeout=300)
-    b = subprocess.run([EXE, "4096", "10", "--strict", "--jsub", "1"], capture_output=True, text=True, timeout=300)
-    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
     line = lambda out: [l for l in out.splitlines() if l.startswith("checksum")][0]
-    assert line(a.stdout) == line(b.stdout)
+    for cpu_args, gpu_args in (([], ["--sum", "seq", "--jsub", "1"]),
+                               (["--sum", "blocked", "--segments", "16"], ["--jsub", "16"]),
+                               (["--sum", "blocked", "--block", "256", "--segments", "3"], ["--jsub", "3", "--block", "256", "--two-launch"])):
+        a = subprocess.run([cpu, "4096", "10"] + cpu_args, capture_output=True, text=True, timeout=300)
+        b = subprocess.run([EXE, "4096", "10", "--strict"] + gpu_args, capture_output=True, text=True, timeout=300)
+        assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+        assert line(a.stdout) == line(b.stdout), (cpu_args, gpu_args)

@@ -27,11 +27,14 @@ WORKER = textwrap.dedent("""
     eng.set_option(nb.OPT_JSUB, {jsub})
     eng.set_option(nb.OPT_OVERLAP, {overlap})
     pos, vel = nb.make_bodies(n, seed=33)
+    f = eng.forces(pos)                      # every process gets all N force words (the other ranks' rows are gathered)
     eng.upload(pos, vel)
     eng.step(0.01, steps)
     p, v = eng.download()
     cfg = eng.config
     assert cfg["nranks"] == world and cfg["rank"] == rank
+    if rank == world - 1:
+        np.save({out!r} + "_force.npy", f)
     if rank == 0:
         np.save({out!r} + "_pos.npy", p); np.save({out!r} + "_vel.npy", v)
     eng.close()
@@ -48,7 +51,7 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,overlap", [(2, 1), (3, 0)])
+@pytest.mark.parametrize("world,overlap", [(2, 1), (3, 0), (3, 2)])
 def test_two_processes_one_gpu_host_transport(nb, tmp_path, world, overlap):
     n, steps, jsub = 12000 + 7, 3, 2
     out = str(tmp_path / "mp")
@@ -69,6 +72,7 @@ def test_two_processes_one_gpu_host_transport(nb, tmp_path, world, overlap):
     try:
         one.set_option(nb.OPT_JSUB, jsub)
         one.set_option(nb.OPT_JSLICES, world)
+        wf = one.forces(pos)
         one.upload(pos, vel)
         one.step(0.01, steps)
         wp, wv = one.download()
@@ -76,3 +80,4 @@ def test_two_processes_one_gpu_host_transport(nb, tmp_path, world, overlap):
         one.close()
     assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
     assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32))
+    assert np.array_equal(np.load(out + "_force.npy").view(np.uint32), wf.view(np.uint32))

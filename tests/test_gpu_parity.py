@@ -1,16 +1,20 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
 
-Two bars, both written out here:
-  * STRICT arithmetic (NBODY_ARITH_STRICT / _REFERENCE_STRICT): every operation is
-    IEEE-exact, so the GPU must equal the oracle BIT FOR BIT — forces, and
-    positions/velocities after any number of steps, for every delivery variant,
-    register blocking and segmentation.
-  * FAST arithmetic (v_rsq_f32, <= 1 ulp; the timed mode): the north_star's 1e-5
-    relative fp32 tolerance on single-pass forces (max-norm), and on positions after
-    the fixed step count in max-norm and in the median; element-wise it is compared
-    with the spread two CPU restatements show when their 1/sqrt differs by 1 ulp
-    (the dynamics with eps = 1e-9 amplify any last-bit difference — see DESIGN.md
-    "Parity").
+The engine's summation order is part of the contract: sources are cut into segments, a segment is summed in
+blocks of K = 1024 sources (two levels), segments are added in ascending order (include/nbody.h NBODY_SUM_BLOCKED;
+the reference's own remedy for long fp32 sums is 16 partials + a tree, S/fxyz.vhd:129-145).  The oracle restates
+exactly that order (oracle.order(...), REF_SUM_BLOCKED), so every test below runs the configuration the engine
+chooses BY ITSELF — the one bench.py times — unless it says otherwise.
+
+Bars, all written out here:
+  * STRICT arithmetic (NBODY_ARITH_STRICT / _REFERENCE_STRICT): every operation is IEEE-exact, so the GPU must
+    equal the oracle BIT FOR BIT — forces, and positions/velocities after any number of steps, for every delivery
+    variant, register blocking, segmentation and block length.
+  * FAST arithmetic (v_rsq_f32, <= 1 ulp; the timed mode): 1e-5 (the north_star's tolerance) on the force of EVERY
+    row, relative to that row's own force, against the same-order oracle AND against an fp64 evaluation; after one
+    step on every body's velocity and position relative to the terms of its own update.  After many steps the
+    dynamics (eps = 1e-9, close pairs) amplify any last-bit difference: there the bar is bit-exactness in strict
+    mode, and for the fast mode a comparison with the spread of two CPU runs whose 1/sqrt differ by <= 1 ulp.
 """
 import numpy as np
 import pytest
@@ -28,6 +32,21 @@ def bits(a):
 
 def maxnorm_rel(a, b):
     return float(np.abs(a[:, :3].astype(np.float64) - b[:, :3]).max() / np.abs(b[:, :3]).max())
+
+
+def row_rel(a, b):
+    """per row: |a_i - b_i|_2 / |b_i|_2 — the error of each body's force relative to that body's own force"""
+    a64, b64 = a[:, :3].astype(np.float64), b[:, :3].astype(np.float64)
+    return np.sqrt(((a64 - b64) ** 2).sum(1)) / np.maximum(np.sqrt((b64 ** 2).sum(1)), 1e-300)
+
+
+def oracle_forces(ora, eng, rows, src=None, d2=O.D2_FMA3, rsqrt=O.RSQRT_F64):
+    """the oracle in the order the engine is configured for"""
+    return ora.forces_order(rows, src, order_=O.order(d2=d2, rsqrt=rsqrt, **eng.order))
+
+
+def oracle_step(ora, eng, pos, vel, dt, steps, rsqrt=O.RSQRT_F64):
+    ora.step_order(pos, vel, dt, steps, order_=O.order(rsqrt=rsqrt, **eng.order))
 
 
 @pytest.fixture()
@@ -49,8 +68,9 @@ def engine_factory(nb):
 VARIANTS = ["smem", "lds", "readlane"]
 
 
-def set_variant(nb, eng, variant, iblock, jsub=1, jslices=1, arith=None, tile=None):
-    eng.set_option(nb.OPT_VARIANT, {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE}[variant])
+def set_variant(nb, eng, variant, iblock, jsub=0, jslices=1, arith=None):
+    eng.set_option(nb.OPT_VARIANT, {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE,
+                                    "isa": nb.VARIANT_ISA, "auto": nb.VARIANT_AUTO}[variant])
     eng.set_option(nb.OPT_IBLOCK, iblock)
     eng.set_option(nb.OPT_JSUB, jsub)
     eng.set_option(nb.OPT_JSLICES, jslices)
@@ -58,29 +78,60 @@ def set_variant(nb, eng, variant, iblock, jsub=1, jslices=1, arith=None, tile=No
         eng.set_option(nb.OPT_ARITH, arith)
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 257, 1000, 2085])
+def test_defaults_are_the_timed_configuration(nb, engine_factory):
+    eng = engine_factory(1 << 16)
+    cfg = eng.config
+    assert cfg["variant"] == "isa" and cfg["iblock"] == 1 and cfg["sum_order"] == "blocked" and cfg["sum_block"] == 1024
+    assert cfg["launches_per_step"] == 1 and cfg["nseg"] > 1          # several segments, still one launch per step
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 257, 1000, 1024, 1025, 2085, 5000])
 def test_strict_forces_bit_exact_ragged_sizes(nb, oracle_fast, engine_factory, n):
+    """auto segmentation, blocked sums: every delivery variant, 1 and 4 bodies per lane"""
     pos, _ = nb.make_bodies(n, seed=n + 1)
-    want = oracle_fast.forces_f32(pos, d2=O.D2_FMA3, rsqrt=O.RSQRT_F64)
     eng = engine_factory(n)
     for variant in VARIANTS:
         for iblock in (1, 4):
             set_variant(nb, eng, variant, iblock, arith=nb.ARITH_STRICT)
-            got = eng.forces(pos)
-            assert np.array_equal(bits(got), bits(want)), (variant, iblock)
+            want = oracle_forces(oracle_fast, eng, pos)
+            assert np.array_equal(bits(eng.forces(pos)), bits(want)), (variant, iblock, eng.config)
     set_variant(nb, eng, "smem", 2, arith=nb.ARITH_REFERENCE_STRICT)
-    want_ref = oracle_fast.forces_f32(pos, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64)
+    want_ref = oracle_forces(oracle_fast, eng, pos, d2=O.D2_REFERENCE)
     assert np.array_equal(bits(eng.forces(pos)), bits(want_ref))
+    # the plain sequential sum (what a CPU nbody.c does) stays available: one segment, one accumulator
+    eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_SEQ)
+    eng.set_option(nb.OPT_JSUB, 1)
+    assert eng.config["sum_order"] == "seq"
+    assert np.array_equal(bits(eng.forces(pos)), bits(oracle_fast.forces_f32(pos, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64)))
+
+
+@pytest.mark.parametrize("block", [64, 256, 1024, 4096])
+def test_blocked_sum_block_lengths(nb, oracle_fast, engine_factory, block):
+    """block boundaries inside tiles (K < tile), across tiles, K > segment: all variants, strict bit-exact"""
+    n = 6000 + 13
+    pos, _ = nb.make_bodies(n, seed=17)
+    eng = engine_factory(n, tile=512)
+    eng.set_option(nb.OPT_SUM_BLOCK, block)
+    for variant, iblock, jsub in (("smem", 1, 1), ("smem", 4, 3), ("lds", 2, 2), ("readlane", 2, 5)):
+        set_variant(nb, eng, variant, iblock, jsub=jsub, arith=nb.ARITH_STRICT)
+        assert eng.config["sum_block"] == block
+        want = oracle_forces(oracle_fast, eng, pos)
+        assert np.array_equal(bits(eng.forces(pos)), bits(want)), (variant, iblock, jsub)
+    # the hand-scheduled loop folds its blocks inside the asm loop: same bits as the compiled kernel
+    set_variant(nb, eng, "isa", 0, jsub=2, arith=nb.ARITH_FMA3)
+    assert eng.config["variant"] == "isa"
+    a = eng.forces(pos)
+    set_variant(nb, eng, "smem", 1, jsub=2, arith=nb.ARITH_FMA3)
+    assert np.array_equal(bits(a), bits(eng.forces(pos)))
 
 
 @pytest.mark.parametrize("tile", [256, 512, 1024])
 def test_strict_lds_tiles(nb, oracle_fast, engine_factory, tile):
     n = 3000
     pos, _ = nb.make_bodies(n, seed=5)
-    want = oracle_fast.forces_f32(pos)
     eng = engine_factory(n, tile=tile)
     set_variant(nb, eng, "lds", 2, arith=nb.ARITH_STRICT)
-    assert np.array_equal(bits(eng.forces(pos)), bits(want))
+    assert np.array_equal(bits(eng.forces(pos)), bits(oracle_forces(oracle_fast, eng, pos)))
 
 
 def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engine_factory):
@@ -91,59 +142,60 @@ def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engin
     ref = None
     for variant in VARIANTS:
         for iblock in (1, 2, 4):
-            set_variant(nb, eng, variant, iblock, arith=nb.ARITH_FMA3)
+            set_variant(nb, eng, variant, iblock, jsub=1, arith=nb.ARITH_FMA3)
             got = eng.forces(pos)
             if ref is None:
                 ref = got
             assert np.array_equal(bits(got), bits(ref)), (variant, iblock)
-    set_variant(nb, eng, "smem", 8, arith=nb.ARITH_FMA3)
+    set_variant(nb, eng, "smem", 8, jsub=1, arith=nb.ARITH_FMA3)
     assert np.array_equal(bits(eng.forces(pos)), bits(ref))
     # the hand-scheduled ISA loop (both code-placement phases): same operations, same order, same bits
     for phase in (0, 1):
-        eng.set_option(nb.OPT_VARIANT, nb.VARIANT_ISA)
+        set_variant(nb, eng, "isa", 0, jsub=1)
         eng.set_option(nb.OPT_ISA_PHASE, phase)
         assert eng.config["variant"] == "isa" and eng.config["iblock"] == 1
         assert np.array_equal(bits(eng.forces(pos)), bits(ref)), phase
         for jsub, jsl in ((3, 1), (2, 5)):
-            eng.set_option(nb.OPT_JSUB, jsub)
-            eng.set_option(nb.OPT_JSLICES, jsl)
+            set_variant(nb, eng, "isa", 0, jsub=jsub, jslices=jsl)
             got = eng.forces(pos)
-            eng.set_option(nb.OPT_VARIANT, nb.VARIANT_SMEM)
+            set_variant(nb, eng, "smem", 1, jsub=jsub, jslices=jsl)
             assert np.array_equal(bits(got), bits(eng.forces(pos))), (phase, jsub, jsl)
-            eng.set_option(nb.OPT_VARIANT, nb.VARIANT_ISA)
-        eng.set_option(nb.OPT_JSUB, 1)
-        eng.set_option(nb.OPT_JSLICES, 1)
-    want = oracle_fast.forces_f32(pos)
+    eng.set_option(nb.OPT_ISA_PHASE, 1)
+    set_variant(nb, eng, "smem", 1, jsub=1)
+    want = oracle_forces(oracle_fast, eng, pos)
     f64 = oracle_fast.forces_f64_from_f32(pos)
-    assert maxnorm_rel(ref, want) < TOL
-    # against the fp64 arbiter the GPU is as good as the CPU fp32 path
-    assert maxnorm_rel(ref, f64) < max(2 * maxnorm_rel(want, f64), 2e-6)
+    assert row_rel(ref, want).max() < TOL and row_rel(ref, f64).max() < TOL
     assert np.all(ref[:, 3] == 0)   # S/compute_store.vhd:242: the 4th word is 0
 
 
-@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 100, 1031])
-def test_isa_loop_equals_compiled_kernel_ragged(nb, engine_factory, n):
-    """Default (hand-scheduled ISA loop, groups of 8 sources + scalar tail) vs the hipcc-scheduled kernel: same bits."""
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 100, 1031, 1024, 2047, 2056, 3000])
+@pytest.mark.parametrize("summ", ["blocked", "seq"])
+def test_isa_loop_equals_compiled_kernel_ragged(nb, engine_factory, n, summ):
+    """Default (hand-scheduled ISA loop, groups of 8 sources + scalar tail, block folds inside the loop) vs the
+    hipcc-scheduled kernel: same bits — forces and three steps, one segment and the auto segmentation."""
     pos, vel = nb.make_bodies(n, seed=100 + n)
     eng = engine_factory(n)
-    eng.set_option(nb.OPT_JSUB, 1)
-    assert eng.config["variant"] == "isa"
-    a = eng.forces(pos)
-    eng.upload(pos, vel)
-    eng.step(0.01, 3)
-    pa, va = eng.download()
-    eng.set_option(nb.OPT_VARIANT, nb.VARIANT_SMEM)
-    assert eng.config["variant"] == "smem"
-    assert np.array_equal(bits(a), bits(eng.forces(pos)))
-    eng.upload(pos, vel)
-    eng.step(0.01, 3)
-    pb, vb = eng.download()
-    assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(va), bits(vb))
+    eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED if summ == "blocked" else nb.SUM_SEQ)
+    eng.set_option(nb.OPT_SUM_BLOCK, 64)            # several blocks even at these sizes
+    for jsub in (1, 0):
+        set_variant(nb, eng, "auto", 0, jsub=jsub)
+        assert eng.config["variant"] == "isa"
+        a = eng.forces(pos)
+        eng.upload(pos, vel)
+        eng.step(0.01, 3)
+        pa, va = eng.download()
+        set_variant(nb, eng, "smem", 1, jsub=jsub)
+        assert eng.config["variant"] == "smem"
+        assert np.array_equal(bits(a), bits(eng.forces(pos)))
+        eng.upload(pos, vel)
+        eng.step(0.01, 3)
+        pb, vb = eng.download()
+        assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(va), bits(vb))
 
 
 def test_segmentation_matches_host_mirror_bitwise(nb, oracle_fast, engine_factory):
     """jslices x jsub segments combined in ascending order == the Python mirror of the decomposition
-    (mini-nbody_amd/sharding.py) driven by the oracle, bit for bit in strict mode."""
+    (mini-nbody_amd/sharding.py) driven by the oracle segment by segment, and == the oracle's own order function."""
     n = 5000
     pos, _ = nb.make_bodies(n, seed=3)
     eng = engine_factory(n)
@@ -155,9 +207,45 @@ def test_segmentation_matches_host_mirror_bitwise(nb, oracle_fast, engine_factor
         for q in range(nsl):
             for t in range(sub):
                 b, e = nb.sharding.segment_bounds(q, t, n, nsl, sub)
-                parts.append(oracle_fast.forces_f32(pos, pos[b:e]))
+                parts.append(oracle_fast.forces_f32(pos, pos[b:e], summ=O.SUM_BLOCKED))
         want = nb.sharding.combine_ascending(parts)
         assert np.array_equal(bits(got), bits(want)), (nsl, sub)
+        assert np.array_equal(bits(got), bits(oracle_forces(oracle_fast, eng, pos))), (nsl, sub)
+
+
+def test_one_launch_combine_equals_combine_kernel(nb, engine_factory):
+    """The in-launch combine (last-arriving workgroup adds the partial sums, finish_rows in nbody_kernels.hpp) against the
+    two-launch form (combine_kernel): same bits for every variant and shape, and over many steps — the partial buffers are
+    rewritten every step, so a stale read of another workgroup's partial would show as a mismatch."""
+    for n, steps in ((300, 20), (4099, 30), (20000, 40), (70001, 12)):
+        pos, vel = nb.make_bodies(n, seed=n)
+        eng = engine_factory(n)
+        for variant, iblock, jsub, jsl in (("auto", 0, 0, 1), ("smem", 4, 5, 3), ("lds", 2, 7, 1), ("readlane", 2, 2, 8), ("auto", 0, 64, 1)):
+            out = {}
+            for fuse in (1, 0):
+                set_variant(nb, eng, variant, iblock, jsub=jsub, jslices=jsl)
+                eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+                assert eng.config["launches_per_step"] == (1 if fuse or eng.config["nseg"] == 1 else 2)
+                f = eng.forces(pos)
+                eng.upload(pos, vel)
+                eng.step(0.01, steps)
+                p1, v1 = eng.download()
+                eng.step(0.01, 3)                      # odd continuation: eager launches after the graph pairs
+                out[fuse] = (f,) + (p1, v1) + eng.download()
+            for x, y in zip(out[1], out[0]):
+                assert np.array_equal(bits(x), bits(y)), (n, variant, iblock, jsub, jsl)
+    # fp64 words (two 16-byte stores per partial)
+    n = 5000
+    pos, vel = nb.make_bodies(n, seed=2, dtype=np.float64)
+    eng = engine_factory(n, fp64=True)
+    out = {}
+    for fuse in (1, 0):
+        eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+        eng.set_option(nb.OPT_JSUB, 6)
+        eng.upload(pos, vel)
+        eng.step(0.01, 9)
+        out[fuse] = eng.download()
+    assert np.array_equal(bits(out[1][0]), bits(out[0][0])) and np.array_equal(bits(out[1][1]), bits(out[0][1]))
 
 
 def test_fpga16_order(nb, oracle_fast, engine_factory):
@@ -175,23 +263,31 @@ def test_fpga16_order(nb, oracle_fast, engine_factory):
 
 
 def test_bodyForce_integrate_config1_shape(nb, oracle_fast, engine_factory):
-    """BASELINE config 1's shape (N = 4096, 10 iterations) through the host-pointer entry points."""
+    """BASELINE config 1's shape (N = 4096, 10 iterations) through the host-pointer entry points, the engine's own
+    configuration; and with one sequential sum against the plain CPU loop."""
     n, dt, iters = 4096, 0.01, 10
-    pos, vel = nb.make_bodies(n)
-    opos, ovel = pos.copy(), vel.copy()
-    eng = engine_factory(n)
-    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
-    eng.set_option(nb.OPT_JSUB, 1)          # one source segment == the oracle's single sequential sum
-    for _ in range(iters):
-        eng.bodyForce(pos, vel, dt)
-        eng.integrate(pos, vel, dt)
-        oracle_fast.bodyForce(opos, ovel, dt)
-        oracle_fast.integrate(opos, ovel, dt)
-    assert np.array_equal(bits(pos), bits(opos))
-    assert np.array_equal(bits(vel), bits(ovel))
+    for seq in (False, True):
+        pos, vel = nb.make_bodies(n)
+        opos, ovel = pos.copy(), vel.copy()
+        eng = engine_factory(n)
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        if seq:
+            eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_SEQ)
+            eng.set_option(nb.OPT_JSUB, 1)
+        for _ in range(iters):
+            eng.bodyForce(pos, vel, dt)
+            eng.integrate(pos, vel, dt)
+        if seq:
+            for _ in range(iters):
+                oracle_fast.bodyForce(opos, ovel, dt)
+                oracle_fast.integrate(opos, ovel, dt)
+        else:
+            oracle_step(oracle_fast, eng, opos, ovel, dt, iters)
+        assert np.array_equal(bits(pos), bits(opos)), seq
+        assert np.array_equal(bits(vel), bits(ovel)), seq
 
 
-@pytest.mark.parametrize("jsub", [1, 4])
+@pytest.mark.parametrize("jsub", [0, 1, 4])
 def test_step_loop_strict_bit_exact(nb, oracle_fast, engine_factory, jsub):
     n, dt, steps = 4096, 0.01, 10
     pos, vel = nb.make_bodies(n)
@@ -201,57 +297,52 @@ def test_step_loop_strict_bit_exact(nb, oracle_fast, engine_factory, jsub):
     eng.upload(pos, vel)
     eng.step(dt, steps)
     gp, gv = eng.download()
-    if jsub == 1:
-        op, ov = pos.copy(), vel.copy()
-        oracle_fast.step(op, ov, dt, steps)
-    else:
-        op, ov = pos.copy(), vel.copy()
-        dtf = np.float32(dt)
-        for _ in range(steps):
-            parts = []
-            for t in range(jsub):
-                b, e = nb.sharding.segment_bounds(0, t, n, 1, jsub)
-                parts.append(oracle_fast.forces_f32(op, op[b:e]))
-            acc = nb.sharding.combine_ascending(parts)
-            # kick and drift with one rounding each (fma): emulate in float64, exact for fp32 inputs
-            ov[:, :3] = (dtf.astype(np.float64) * acc[:, :3].astype(np.float64) + ov[:, :3]).astype(np.float32)
-            op[:, :3] = (ov[:, :3].astype(np.float64) * dtf.astype(np.float64) + op[:, :3]).astype(np.float32)
+    op, ov = pos.copy(), vel.copy()
+    oracle_step(oracle_fast, eng, op, ov, dt, steps)
     assert np.array_equal(bits(gp), bits(op))
     assert np.array_equal(bits(gv), bits(ov))
     assert np.all(gp[:, 3] == 1) and np.all(gv[:, 3] == 0)
 
 
 def test_step_loop_fast_within_tolerance(nb, oracle_fast, engine_factory):
-    """The timed mode (v_rsq_f32) after the fixed step count, N = 4096, 10 steps, same summation order
-    as the oracle (one source segment) so that the only difference is the 1-ulp 1/sqrt."""
+    """The timed mode (v_rsq_f32), the engine's own configuration, N = 4096.
+
+    One step — no amplification yet — is held to 1e-5 on EVERY body, relative to the terms of that body's own update:
+    |dv_i| <= 1e-5 max(|v_i|, dt |F_i|) and |dr_i| <= 1e-5 max(|r_i|, dt |v'_i|).  (A component-wise relative error
+    |a-b|/|b| is the wrong norm here: a coordinate that happens to lie near zero makes it arbitrarily large for an
+    absolute error far below the body's own scale; round 1 worked around that with quantiles.)
+    Ten steps: close pairs (eps = 1e-9) amplify last-bit differences — two CPU runs whose 1/sqrt differ by <= 1 ulp
+    disagree by far more than 1e-5 on some bodies — so the fixed-step-count bar is bit-exactness in strict mode
+    (test_step_loop_strict_bit_exact, test_config2_n65536) and here: median within 1e-5 and the tails no worse than
+    4x that CPU-vs-CPU envelope."""
     n, dt, steps = 4096, 0.01, 10
     pos, vel = nb.make_bodies(n)
     eng = engine_factory(n)
-    eng.set_option(nb.OPT_JSUB, 1)
+    eng.upload(pos, vel)
+    f0 = eng.forces(pos)
     eng.upload(pos, vel)
     eng.step(dt, 1)
-    g1, _ = eng.download()
+    g1, gv1 = eng.download()
     eng.step(dt, steps - 1)
     gp, gv = eng.download()
     o1, ov1 = pos.copy(), vel.copy()
-    oracle_fast.step(o1, ov1, dt, 1)
+    oracle_step(oracle_fast, eng, o1, ov1, dt, 1)
     op, ov = pos.copy(), vel.copy()
-    oracle_fast.step(op, ov, dt, steps)
-    # a second CPU restatement whose 1/sqrt differs by <= 1 ulp: the envelope of "equally right" answers
-    e1, ev1 = pos.copy(), vel.copy()
-    oracle_fast.step(e1, ev1, dt, 1, rsqrt=O.RSQRT_DIVSQRT)
+    oracle_step(oracle_fast, eng, op, ov, dt, steps)
     ep, ev = pos.copy(), vel.copy()
-    oracle_fast.step(ep, ev, dt, steps, rsqrt=O.RSQRT_DIVSQRT)
+    oracle_step(oracle_fast, eng, ep, ev, dt, steps, rsqrt=O.RSQRT_DIVSQRT)
+
+    def inf(a):
+        return np.abs(a[:, :3].astype(np.float64)).max(1)
+
+    dtf = float(np.float32(dt))
+    assert np.all(inf(gv1 - ov1.astype(np.float64)) <= TOL * np.maximum(inf(vel), dtf * inf(f0)))
+    assert np.all(inf(g1 - o1.astype(np.float64)) <= TOL * np.maximum(inf(pos), dtf * inf(ov1)))
+    assert maxnorm_rel(g1, o1) < TOL
 
     def elementwise(a, b):
         return np.abs(a[:, :3] - b[:, :3]) / np.maximum(np.abs(b[:, :3]), 1e-30)
 
-    # one step: no amplification yet -> the plain tolerance, in max-norm and for 99 % of the components
-    assert maxnorm_rel(g1, o1) < TOL
-    el1, env1 = elementwise(g1, o1), elementwise(e1, o1)
-    assert np.quantile(el1, 0.99) < TOL
-    assert np.quantile(el1, 0.999) < 4 * max(np.quantile(env1, 0.999), TOL)
-    # fixed step count: median within tolerance, and no worse than the CPU-vs-CPU envelope
     el, env = elementwise(gp, op), elementwise(ep, op)
     assert np.median(el) < TOL
     assert np.isfinite(gp).all() and np.isfinite(gv).all()
@@ -259,73 +350,169 @@ def test_step_loop_fast_within_tolerance(nb, oracle_fast, engine_factory):
     assert np.quantile(el, 0.99) < 4 * max(np.quantile(env, 0.99), TOL)
 
 
-def test_config2_n65536(nb, oracle_fast, engine_factory):
-    """BASELINE config 2: N = 65536, LDS tile = 256 and the default SMEM variant.
-    Strict mode bit-exact over 3 steps (1.3e10 pairs on the host); 100 steps on the GPU stay finite
-    and agree between the two variants bit for bit."""
-    n, dt = 65536, 0.01
+def test_config2_n65536(nb, oracle_fast, engine_factory, capsys):
+    """BASELINE config 2 in full: N = 65536, 100 steps, one GPU.  Strict arithmetic in the engine's own configuration
+    (64 source segments, blocked sums, one launch per step) and with the LDS tile = 256 delivery the config names: bit-exact
+    against the oracle after all 100 steps (4.3e11 pairs on the host cores).  Fast mode (the timed arithmetic, ISA loop):
+    forces of the initial state within 1e-5 on every row against the same-order oracle and against fp64; the 100-step
+    deviation from the strict run is printed for the record (the dynamics amplify last-bit differences)."""
+    n, dt, steps = 65536, 0.01, 100
     pos, vel = nb.make_bodies(n)
     eng = engine_factory(n, tile=256)
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    cfg = eng.config
+    assert cfg["nseg"] > 1 and cfg["sum_order"] == "blocked" and cfg["launches_per_step"] == 1
     op, ov = pos.copy(), vel.copy()
-    oracle_fast.step(op, ov, dt, 3)
-    for variant in ("lds", "smem"):
-        set_variant(nb, eng, variant, 4, jsub=1, arith=nb.ARITH_STRICT)
-        eng.upload(pos, vel)
-        eng.step(dt, 3)
-        gp, gv = eng.download()
-        assert np.array_equal(bits(gp), bits(op)), variant
-        assert np.array_equal(bits(gv), bits(ov)), variant
-    out = []
-    for variant in ("lds", "smem"):
-        set_variant(nb, eng, variant, 0, jsub=0, arith=nb.ARITH_FMA3)
-        eng.set_option(nb.OPT_JSUB, 8)
-        eng.upload(pos, vel)
-        eng.step(dt, 100)
-        out.append(eng.download())
-    assert np.isfinite(out[0][0]).all()
-    assert np.array_equal(bits(out[0][0]), bits(out[1][0]))
-    # fast-mode forces of the initial state: same summation order as the oracle (one segment) -> only the
-    # 1-ulp 1/sqrt differs; and against the fp64 arbiter the GPU is as accurate as the CPU fp32 path
-    # (at this N two fp32 sums in DIFFERENT orders already differ by ~1e-5 of the largest force).
-    set_variant(nb, eng, "smem", 4, jsub=1, arith=nb.ARITH_FMA3)
+    oracle_step(oracle_fast, eng, op, ov, dt, steps)
+    eng.upload(pos, vel)
+    eng.step(dt, steps)
+    gp, gv = eng.download()
+    assert np.array_equal(bits(gp), bits(op)) and np.array_equal(bits(gv), bits(ov))
+    set_variant(nb, eng, "lds", 2, jsub=cfg["jsub"], arith=nb.ARITH_STRICT)      # LDS tile = 256, same segmentation
+    assert eng.config["variant"] == "lds" and eng.config["tile"] == 256
+    eng.upload(pos, vel)
+    eng.step(dt, steps)
+    lp, lv = eng.download()
+    assert np.array_equal(bits(lp), bits(op)) and np.array_equal(bits(lv), bits(ov))
+    # the timed arithmetic
+    set_variant(nb, eng, "auto", 0, jsub=0, arith=nb.ARITH_FMA3)
+    assert eng.config["variant"] == "isa" and eng.config["nseg"] == cfg["nseg"]
     f = eng.forces(pos)
-    want = oracle_fast.forces_f32(pos)
+    want = oracle_forces(oracle_fast, eng, pos)
     f64 = oracle_fast.forces_f64_from_f32(pos)
-    assert maxnorm_rel(f, want) < TOL
-    assert maxnorm_rel(f, f64) < 2 * maxnorm_rel(want, f64) + 1e-6
-    set_variant(nb, eng, "smem", 0, jsub=0, arith=nb.ARITH_FMA3)      # the auto configuration (segmented)
-    assert maxnorm_rel(eng.forces(pos), f64) < 2 * maxnorm_rel(want, f64) + 1e-6
+    r_same, r_f64 = row_rel(f, want), row_rel(f, f64)
+    assert r_same.max() < TOL and r_f64.max() < TOL, (r_same.max(), r_f64.max())
+    eng.upload(pos, vel)
+    eng.step(dt, steps)
+    fp, fv = eng.download()
+    assert np.isfinite(fp).all() and np.isfinite(fv).all()
+    set_variant(nb, eng, "lds", 2, jsub=cfg["jsub"], arith=nb.ARITH_FMA3)
+    eng.upload(pos, vel)
+    eng.step(dt, steps)
+    assert np.array_equal(bits(eng.download()[0]), bits(fp))                     # LDS tile = 256 == ISA loop, fast mode
+    el = np.abs(fp[:, :3] - op[:, :3]) / np.maximum(np.abs(op[:, :3]), 1e-30)
+    with capsys.disabled():
+        print("\n[config 2] N=65536: forces fast vs same-order oracle max row rel %.2e, vs fp64 %.2e; after 100 steps fast vs strict: "
+              "max-norm %.2e, median component %.2e, 99%% %.2e" % (r_same.max(), r_f64.max(), maxnorm_rel(fp, op), np.median(el), np.quantile(el, 0.99)))
+    assert np.median(el) < TOL
 
 
-def test_headline_size_row_sample_and_properties(nb, oracle_fast, engine_factory):
-    """N = 1,048,576 (BASELINE config 3): one CPU pass is 1.1e12 pairs, so parity is row-sampled
-    (SURVEY.md §7 "Hard parts"): 1024 rows incl. the first and last body, all N sources, strict mode
-    bit-exact and fast mode within tolerance; plus size-independent properties on the full state."""
+def shard_edge_rows(n, shards, width):
+    """(first, count) windows holding the first and last `width` rows of each of `shards` equal shards"""
+    out = []
+    per = n // shards
+    for q in range(shards):
+        out.append((q * per, width))
+        out.append(((q + 1) * per - width, width))
+    return out
+
+
+def test_headline_size_row_sample_and_properties(nb, oracle_fast, engine_factory, capsys):
+    """N = 1,048,576 (BASELINE config 3) in the configuration bench.py times (ISA loop, 8 source segments, blocked sums,
+    one launch per step): one CPU pass is 1.1e12 pairs, so parity is row-sampled (SURVEY.md §7 "Hard parts") — 1280 rows:
+    the first and last 64 rows of each of 8 shards of 131072 (the 8-GPU shard edges) plus 256 in the middle, all N sources.
+    Strict: bit-exact.  Fast: every sampled row within 1e-5 of the same-order oracle AND of fp64.  Then size-independent
+    properties of one timed-mode step on the full state."""
     n = 1 << 20
     pos, vel = nb.make_bodies(n)
     eng = engine_factory(n)
+    cfg = eng.config
+    assert cfg["variant"] == "isa" and cfg["nseg"] == 8 and cfg["sum_block"] == 1024 and cfg["launches_per_step"] == 1
     eng.upload(pos, vel)
-    sample = [(0, 256), (n // 2 - 128, 256), (n - 512, 512)]
+    sample = shard_edge_rows(n, 8, 64) + [(n // 2 - 128, 256)]
+    assert sum(c for _, c in sample) >= 1024
     eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
-    eng.set_option(nb.OPT_JSUB, 1)
+    assert eng.config["nseg"] == 8
     for first, cnt in sample:
         got = eng.forces_rows(first, cnt)
-        want = oracle_fast.forces_f32(pos[first:first + cnt], pos)
+        want = oracle_forces(oracle_fast, eng, pos[first:first + cnt], pos)
         assert np.array_equal(bits(got), bits(want)), first
     eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
-    for first, cnt in sample[:1]:
+    assert eng.config == cfg
+    worst_same = worst_f64 = 0.0
+    for first, cnt in sample:
         got = eng.forces_rows(first, cnt)
-        want = oracle_fast.forces_f32(pos[first:first + cnt], pos)
-        assert maxnorm_rel(got, want) < TOL
+        want = oracle_forces(oracle_fast, eng, pos[first:first + cnt], pos)
+        f64 = oracle_fast.forces_f64_from_f32(pos[first:first + cnt], pos)
+        worst_same = max(worst_same, row_rel(got, want).max())
+        worst_f64 = max(worst_f64, row_rel(got, f64).max())
+    with capsys.disabled():
+        print("\n[config 3] N=1048576 timed configuration %s: worst sampled row vs same-order oracle %.2e, vs fp64 %.2e" % (cfg, worst_same, worst_f64))
+    assert worst_same < TOL and worst_f64 < TOL
     # properties: a step moves exactly r' = r + v'*dt (checked from the downloaded state), w carried
     eng.step(0.01, 1)
     p1, v1 = eng.download()
     dt = np.float64(np.float32(0.01))
     assert np.array_equal(bits(p1[:, :3]), bits((v1[:, :3].astype(np.float64) * dt + pos[:, :3]).astype(np.float32)))
     assert np.all(p1[:, 3] == 1) and np.all(v1[:, 3] == 0) and np.isfinite(v1).all()
+    # the kick used the same forces the row sample saw: v' = fma(dt, F, v) exactly, on the sampled rows
+    first, cnt = sample[-1]
+    eng.upload(pos, vel)
+    f = eng.forces_rows(first, cnt)
+    assert np.array_equal(bits(v1[first:first + cnt, :3]),
+                          bits((dt * f[:, :3].astype(np.float64) + vel[first:first + cnt, :3]).astype(np.float32)))
     # momentum: unit masses and antisymmetric pair terms -> sum_i F_i ~ 0 relative to sum_i |F_i|
     dv = (v1[:, :3].astype(np.float64) - vel[:, :3]) / dt
     assert np.abs(dv.sum(0)).max() / np.abs(dv).sum() < 1e-4
+
+
+def test_config4_workload_eight_virtual_ranks(nb, oracle_fast, engine_factory, monkeypatch):
+    """BASELINE config 4's workload on this box's one GPU: N = 1,048,576 sharded over 8 (virtual) ranks of 131072 bodies,
+    each rank's own-slice launch first, then the arrived slices — the schedule of the 8-GPU job with peer copies in place
+    of xGMI.  Two steps must equal one GPU configured with the same segmentation (8 slices x the same sub) bit for bit, and
+    the forces on rows at the shard edges must be within 1e-5 of the oracle in that order and of fp64."""
+    monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
+    n, P, dt, steps = 1 << 20, 8, 0.01, 2
+    pos, vel = nb.make_bodies(n)
+    multi = engine_factory(n, ngpus=P)
+    cfg = multi.config
+    assert cfg["nranks"] == P and cfg["n_local"] == n // P and cfg["launches_per_step"] == 2
+    multi.upload(pos, vel)
+    multi.step(dt, steps)
+    mp, mv = multi.download()
+    one = engine_factory(n)
+    one.set_option(nb.OPT_JSLICES, P)
+    one.set_option(nb.OPT_JSUB, cfg["jsub"])
+    assert one.config["nseg"] == cfg["nseg"]
+    one.upload(pos, vel)
+    one.step(dt, steps)
+    wp, wv = one.download()
+    assert np.array_equal(bits(mp), bits(wp)) and np.array_equal(bits(mv), bits(wv))
+    one.upload(pos, vel)
+    worst = 0.0
+    for first, cnt in shard_edge_rows(n, P, 32):
+        got = one.forces_rows(first, cnt)
+        want = oracle_forces(oracle_fast, one, pos[first:first + cnt], pos)
+        f64 = oracle_fast.forces_f64_from_f32(pos[first:first + cnt], pos)
+        worst = max(worst, row_rel(got, want).max(), row_rel(got, f64).max())
+    assert worst < TOL, worst
+
+
+def test_config5_workload_fp64(nb, oracle_fast, engine_factory):
+    """BASELINE config 5's workload on one GPU: N = 4,194,304 fp64, one step (1.8e13 pairs, ~11 s).  Row-sampled forces
+    (nbody_forces_rows_d) against the fp64 oracle at the 8-GPU shard edges, then the size-independent properties of the step."""
+    n = 1 << 22
+    pos, vel = nb.make_bodies(n, dtype=np.float64)
+    eng = engine_factory(n, fp64=True)
+    cfg = eng.config
+    assert cfg["variant"] == "isa" and cfg["sum_order"] == "seq" and cfg["launches_per_step"] == 1
+    eng.upload(pos, vel)
+    for first, cnt in shard_edge_rows(n, 8, 16) + [(n // 2 - 64, 128)]:
+        got = eng.forces_rows(first, cnt)
+        want = oracle_fast.forces_f64(pos[first:first + cnt], pos)
+        assert row_rel(got, want).max() < 1e-11, first        # different summation orders in fp64: ~sqrt(N) * 2^-53
+        assert np.all(got[:, 3] == 0)
+    eng.step(0.01, 1)
+    p1, v1 = eng.download()
+    assert np.isfinite(p1).all() and np.isfinite(v1).all() and np.all(p1[:, 3] == 1) and np.all(v1[:, 3] == 0)
+    # r' = fma(v', dt, r) exactly: check with exact rational arithmetic on a sample (fp64 has no wider host type)
+    from fractions import Fraction
+    for i in (0, 1, n // 3, n - 1):
+        for c in range(3):
+            exact = Fraction(float(v1[i, c])) * Fraction(0.01) + Fraction(float(pos[i, c]))
+            assert float(exact) == p1[i, c], (i, c)
+    dv = (v1[:, :3] - vel[:, :3]) / 0.01
+    assert np.abs(dv.sum(0)).max() / np.abs(dv).sum() < 1e-9
 
 
 def test_translation_property(nb, engine_factory):
@@ -367,11 +554,11 @@ def test_extreme_values_strict_bit_exact(nb, oracle_fast, engine_factory):
     pos[30:34, :3] = pos[29, :3]                           # five coincident bodies
     pos[40, :3] = [1e10, 1e10, 1e10]
     eng = engine_factory(n)
+    eng.set_option(nb.OPT_SUM_BLOCK, 64)                   # several blocks and several segments at this size
     for arith, d2 in ((nb.ARITH_STRICT, O.D2_FMA3), (nb.ARITH_REFERENCE_STRICT, O.D2_REFERENCE)):
         eng.set_option(nb.OPT_ARITH, arith)
-        eng.set_option(nb.OPT_JSUB, 1)
         with np.errstate(all="ignore"):
-            want = oracle_fast.forces_f32(pos, d2=d2, rsqrt=O.RSQRT_F64)
+            want = oracle_forces(oracle_fast, eng, pos, d2=d2)
         got = eng.forces(pos)
         nan_w, nan_g = np.isnan(want), np.isnan(got)
         assert np.array_equal(nan_w, nan_g)
@@ -401,11 +588,10 @@ def test_mailbox_maximum_points(nb, oracle_fast, engine_factory):
     ram_a = nb.mailbox.encode_request(pos)
     eng = engine_factory(n)
     eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
-    eng.set_option(nb.OPT_JSUB, 1)
     ram_b = nb.mailbox.run(eng, ram_a)
     assert ram_b.shape == (n, 4) and nb.mailbox.decode_control(ram_a)["begin"] == 0
     rows = np.r_[0:64, n // 2:n // 2 + 64, n - 64:n]
-    want = oracle_fast.forces_f32(pos[rows], pos)
+    want = oracle_forces(oracle_fast, eng, pos[rows], pos)
     assert np.array_equal(bits(ram_b[rows]), bits(want))
 
 
@@ -418,11 +604,10 @@ def test_mailbox_front_end(nb, oracle_fast, engine_factory):
     assert nb.mailbox.decode_control(ram_a) == dict(begin=1, num_pts=n, ticks=n)
     eng = engine_factory(n)
     eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
-    eng.set_option(nb.OPT_JSUB, 1)
     ram_b = nb.mailbox.run(eng, ram_a, clock_khz=300000)
     ctl = nb.mailbox.decode_control(ram_a)
     assert ctl["begin"] == 0 and ctl["ticks"] >= 1       # S/top_level.vhd:146, 255-263
-    assert np.array_equal(bits(ram_b), bits(oracle_fast.forces_f32(pos)))
+    assert np.array_equal(bits(ram_b), bits(oracle_forces(oracle_fast, eng, pos)))
     assert np.all(ram_b[:, 3] == 0)
     with pytest.raises(nb.NBodyError):                    # BEGIN not set -> nothing to do
         nb.mailbox.run(eng, ram_a)
@@ -436,6 +621,7 @@ def test_fp64_path(nb, oracle_fast, engine_factory):
     f = eng.forces(pos)
     want = oracle_fast.forces_f64(pos)
     assert maxnorm_rel(f, want) < 1e-13
+    assert np.array_equal(bits(eng.forces_rows(100, 300)), bits(f[100:400]))
     for iblock, jsub in ((1, 1), (2, 4), (4, 2)):
         eng.set_option(nb.OPT_IBLOCK, iblock)
         eng.set_option(nb.OPT_JSUB, jsub)
@@ -480,34 +666,42 @@ def test_fp64_isa_loop_equals_compiled_kernel(nb, oracle_fast, engine_factory, n
 
 
 def test_virtual_multi_gpu_schedule_bitwise(nb, oracle_fast, engine_factory, monkeypatch):
-    """The multi-GPU schedule (i-sharding, ring-ordered arrival, per-slice partials, ascending combine,
-    double-buffered positions) with P virtual ranks sharing this box's one GPU; the transfers are peer
-    copies, everything else is the code the 8-GPU run executes.  Must equal one GPU configured with
-    the same segmentation bit for bit, in fast mode, over several steps."""
+    """The multi-GPU schedule (i-sharding, ring-ordered arrival, per-slice partials, ascending combine by the last
+    arriver across the step's launches, double-buffered positions) with P virtual ranks sharing this box's one GPU;
+    the transfers are peer copies, everything else is the code the 8-GPU run executes.  Must equal one GPU configured
+    with the same segmentation bit for bit, in fast mode, over several steps — for every overlap mode (gather first /
+    own slice then the rest / one launch per arriving slice) and for the two-launch combine."""
     monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
     n, dt, steps = 8192 + 5, 0.01, 4
     pos, vel = nb.make_bodies(n, seed=21)
-    results = {}
     for P in (1, 2, 3, 4):
-        for overlap in ((1,) if P == 1 else (1, 0)):
+        one = engine_factory(n)
+        one.set_option(nb.OPT_IBLOCK, 2)
+        one.set_option(nb.OPT_JSUB, 2)
+        one.set_option(nb.OPT_JSLICES, P)
+        one.upload(pos, vel)
+        one.step(dt, steps)
+        wp, wv = one.download()
+        if P == 1:
+            # and against the oracle in that order (strict)
+            one.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+            one.upload(pos, vel)
+            one.step(dt, steps)
+            sp, sv = one.download()
+            op, ov = pos.copy(), vel.copy()
+            oracle_step(oracle_fast, one, op, ov, dt, steps)
+            assert np.array_equal(bits(sp), bits(op)) and np.array_equal(bits(sv), bits(ov))
+        for overlap, fuse in (((1, 1),) if P == 1 else ((1, 1), (0, 1), (2, 1), (1, 0), (2, 0))):
             eng = engine_factory(n, ngpus=P)
             eng.set_option(nb.OPT_IBLOCK, 2)
             eng.set_option(nb.OPT_JSUB, 2)
             eng.set_option(nb.OPT_OVERLAP, overlap)
+            eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
             eng.upload(pos, vel)
             eng.step(dt, steps)
-            results[(P, overlap)] = eng.download()
-            # reference: one GPU, same segmentation
-            one = engine_factory(n)
-            one.set_option(nb.OPT_IBLOCK, 2)
-            one.set_option(nb.OPT_JSUB, 2)
-            one.set_option(nb.OPT_JSLICES, P)
-            one.upload(pos, vel)
-            one.step(dt, steps)
-            wp, wv = one.download()
-            gp, gv = results[(P, overlap)]
-            assert np.array_equal(bits(gp), bits(wp)), (P, overlap)
-            assert np.array_equal(bits(gv), bits(wv)), (P, overlap)
+            gp, gv = eng.download()
+            assert np.array_equal(bits(gp), bits(wp)), (P, overlap, fuse)
+            assert np.array_equal(bits(gv), bits(wv)), (P, overlap, fuse)
 
 
 @pytest.mark.parametrize("fp64", [False, True])
@@ -564,3 +758,33 @@ def test_step_graph_replay_equals_eager(nb, engine_factory):
     for k in (0, 1):
         for x, y in zip(out[1][k], out[0][k]):
             assert np.array_equal(bits(x), bits(y))
+
+
+def test_rccl_calls_on_a_one_rank_communicator(nb, engine_factory):
+    """The RCCL data path of the multi-GPU job — dlopen/dlsym of librccl, ncclCommInitRank, ncclAllGather in place,
+    grouped ncclSend/ncclRecv ring step: argument order and byte counts — executed on this box's one GPU through a
+    one-rank communicator (nbody_init_rank with nranks = 1 and a unique id; a second process on the same device is
+    refused by RCCL, so this is as far as one GPU goes).  nbody_comm_selftest checks every received word."""
+    n = 10000 + 3
+    uid = nb.unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng = engine_factory(n, rank=0, nranks=1, uid=uid)
+    assert eng.info(nb._lib.INFO_HAS_COMM) == 1
+    for comm in (nb.COMM_RING, nb.COMM_ALLGATHER, nb.COMM_AUTO):
+        eng.set_option(nb.OPT_COMM, comm)
+        moved = eng.comm_selftest()
+        assert moved == (n // 2) * 16            # one rank: the all-gather moves nothing, the ring step half the array
+    # the context computes as usual
+    pos, vel = nb.make_bodies(n, seed=1)
+    eng.upload(pos, vel)
+    eng.step(0.01, 2)
+    gp, gv = eng.download()
+    plain = engine_factory(n)
+    plain.upload(pos, vel)
+    plain.step(0.01, 2)
+    wp, wv = plain.download()
+    assert np.array_equal(bits(gp), bits(wp)) and np.array_equal(bits(gv), bits(wv))
+    with pytest.raises(nb.NBodyError):           # no communicator on a plain context
+        plain.comm_selftest()
+    f64 = engine_factory(2001, fp64=True, rank=0, nranks=1, uid=nb.unique_id())
+    assert f64.comm_selftest() == (2001 // 2) * 32

@@ -16,19 +16,27 @@ profiles/r01_sweep_isa.txt):
     — the previous body's accumulates are the wait state, and this was the fastest legal single-chain order in the
     stream harness (ord_defA, 2.63 cycles/instruction).
   * live-in / live-out values are copied into fixed registers (v8-v14, s34) so that the loop's bytes, banks and
-    placement do not depend on hipcc's register allocation around the asm statement; the loop head sits 4*PAD bytes
+    placement do not depend on hipcc's register allocation around the asm statement; the loop head sits 60 bytes
     past a 64-byte line.
+  * a single fp32 accumulator per axis is off by 1e-4 of the force after 2^20 terms; the reference keeps 16 partial
+    sums and an adder tree for the same reason (S/fxyz.vhd:129-145, S/final_adder.vhd:88-104).  Here the sum has two
+    levels: every BLK groups (sum_block / 8, default 128) the three accumulators are added to second-level ones and
+    restart from zero — 3 v_add + 7 v_mov + 4 scalar instructions per 12288 VALU instructions.
 
 Loop shape (one wave, one body i per lane, sources delivered as wave-uniform scalar loads):
-    A = s[36:51], B = s[52:67]: two buffers of 4 bodies {x,y,z,w}; pointer s[68:69], group counter s70, stride s71
+    A = s[36:51], B = s[52:67]: two buffers of 4 bodies {x,y,z,w}; pointer s[68:69], group counter s70, stride s71,
+    groups left s72, groups per block s73
     prologue: load A
-    loop:  wait A | load B | 4 bodies from A (48 VALU) | advance pointer | wait B | load A (next group) | 4 bodies from B
+    block: s70 = min(s72, s73) groups
+      loop:  wait A | load B | 4 bodies from A (48 VALU) | advance pointer | wait B | load A (next group) | 4 bodies from B
+      accumulate the block's last body; a full block is folded into level 2, a short one (the segment's last) is left
+      in level 1 for the caller
     (the load of the group after the last one reads <= 64 bytes past the segment: inside the 1 KiB pad of the arrays)
 The arithmetic and its order per body are exactly pair_f32<0> of nbody_kernels.hpp (sources ascending), so the result
 is bit-identical to the C++ kernels (tests/test_gpu_parity.py).
 
-Variants emitted: NB_FORCE_LOOP_V1 = the product loop (PAD = 15); NB_FORCE_LOOP_V0 = the same instructions one 4-byte
-phase off (PAD = 14), kept only so that the placement effect can be re-measured (NBODY_OPT_ISA_PHASE = 0: 3.4k vs 4.6k G/s).
+Variants emitted: NB_FORCE_LOOP_V1 = the product loop (head 60 bytes past a 64-byte line); NB_FORCE_LOOP_V0 = the same
+instructions one 4-byte phase off (head at 56), kept only so that the placement effect can be re-measured (NBODY_OPT_ISA_PHASE = 0: 3.4k vs 4.6k G/s).
 Bring-up experiments that did not help (16-source groups, base+offset addressing, fused count-down, loads issued
 mid-buffer, other in-body orders) are recorded in DESIGN.md §3.1 and in the git history of this file.
 """
@@ -69,14 +77,23 @@ def body(k, sbase, b):
     ]
 
 
+BX, BY, BZ = "v15", "v16", "v17"        # level-2 accumulators (finished blocks)
+TOT, BLK, FULL = 72, 73, 74             # groups still to do after this block, groups per block, "this block is a full one"
+HEAD_BYTES = 16                         # the four 4-byte scalar instructions between the label `2:` and the loop head
+
+
 def build(pad):
+    """pad: s_nop count after .p2align 6, so that the inner loop's head `1:` sits 4*pad + HEAD_BYTES bytes past a
+    64-byte line (60 for the product loop: every VALU instruction of the loop then starts at 4 mod 8 bytes)."""
     px, py, pz = DSETS[1]
     ins = [
         "v_mov_b32 %s, %%[xi]" % XI, "v_mov_b32 %s, %%[yi]" % YI, "v_mov_b32 %s, %%[zi]" % ZI,
         "v_mov_b32 %s, %%[ax]" % AX, "v_mov_b32 %s, %%[ay]" % AY, "v_mov_b32 %s, %%[az]" % AZ,
+        "v_mov_b32 %s, %%[bx]" % BX, "v_mov_b32 %s, %%[by]" % BY, "v_mov_b32 %s, %%[bz]" % BZ,
         "s_mov_b32 %s, %%[eps]" % EPS,
         "s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1),
-        "s_mov_b32 s%d, %%[groups]" % CNT,
+        "s_mov_b32 s%d, %%[groups]" % TOT,
+        "s_mov_b32 s%d, %%[blk]" % BLK,
         "s_movk_i32 s%d, 0x80" % STRIDE,
         "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1),
     ]
@@ -84,6 +101,12 @@ def build(pad):
     ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
     ins.append(".p2align 6")
     ins += ["s_nop 0"] * pad
+    # ---- one block of the two-level sum: CNT = min(groups left, groups per block) iterations of the inner loop
+    ins.append("2:")
+    ins += ["s_min_u32 s%d, s%d, s%d" % (CNT, TOT, BLK),
+            "s_cmp_eq_u32 s%d, s%d" % (CNT, BLK),
+            "s_cselect_b32 s%d, 1, 0" % FULL,
+            "s_sub_u32 s%d, s%d, s%d" % (TOT, TOT, CNT)]
     ins.append("1:")
     ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
     ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
@@ -95,10 +118,22 @@ def build(pad):
     for b in range(4):
         ins += body(4 + b, B_BASE, b)
     ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b"]
-    # drain: the accumulate of the last body (body 7: d set 1, t register 1); retire the unused prefetch; sums out
+    # the block's last body has not been accumulated yet (body 7: d set 1, t register 1)
     ins += ["v_fma_f32 %s, v%d, v%d, %s" % (AX, px, T2[1], AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, T2[1], AY),
             "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, T2[1], AZ)]
-    ins += ["s_waitcnt lgkmcnt(0)", "v_mov_b32 %%[ax], %s" % AX, "v_mov_b32 %%[ay], %s" % AY, "v_mov_b32 %%[az], %s" % AZ]
+    # a block that stopped short of BLK groups is the segment's last one: its sum stays in level 1 (the caller adds
+    # the < 8 leftover sources to it and folds it)
+    ins += ["s_cmp_eq_u32 s%d, 0" % FULL, "s_cbranch_scc1 3f"]
+    # fold: level 2 += level 1 (ascending block order), level 1 = 0, and again no "previous body"
+    ins += ["v_add_f32_e64 %s, %s, %s" % (BX, BX, AX), "v_add_f32_e64 %s, %s, %s" % (BY, BY, AY),
+            "v_add_f32_e64 %s, %s, %s" % (BZ, BZ, AZ)]
+    ins += ["v_mov_b32 %s, 0" % r for r in (AX, AY, AZ)]
+    ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
+    ins += ["s_cmp_lg_u32 s%d, 0" % TOT, "s_cbranch_scc1 2b"]
+    ins.append("3:")
+    # retire the unused prefetch; sums out
+    ins += ["s_waitcnt lgkmcnt(0)", "v_mov_b32 %%[ax], %s" % AX, "v_mov_b32 %%[ay], %s" % AY, "v_mov_b32 %%[az], %s" % AZ,
+            "v_mov_b32 %%[bx], %s" % BX, "v_mov_b32 %%[by], %s" % BY, "v_mov_b32 %%[bz], %s" % BZ]
     return ins
 
 
@@ -181,9 +216,14 @@ def build_f64(pad):
 
 def check(ins):
     """the hardware rules the loop is built on"""
+    # position of the loop head relative to the 64-byte line set by .p2align 6
+    pre = ins[ins.index(".p2align 6") + 1:ins.index("1:")]
+    head = sum(0 if i.endswith(":") else 4 for i in pre)      # only 4-byte scalar instructions there
+    assert all(i.endswith(":") or i.startswith("s_") for i in pre)
     loop = ins[ins.index("1:"):]
     loop = loop[:loop.index("s_cbranch_scc1 1b") + 1]
     nbytes = 0
+    first_valu = None
     for i in loop:
         if i.endswith(":"):
             continue
@@ -196,18 +236,22 @@ def check(ins):
                 assert len({r & 1 for r in regs}) == 2, i                            # never three same-parity VGPR reads
         if size == 8:
             assert nbytes % 8 == 0, i                                                # 4-byte instructions only in pairs
+            if op.startswith("v_") and first_valu is None:
+                first_valu = (head + nbytes) % 8
         nbytes += size
     assert nbytes % 8 == 0
+    return head % 64, first_valu
 
 
 def main():
-    regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ)]))
-    clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(A_BASE, STRIDE + 1)] + ["scc", "memory"]
+    regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ, BX, BY, BZ)]))
+    clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(A_BASE, FULL + 1)] + ["scc", "memory"]
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_force_loop.py — do not edit.  See that file for the why.\n")
-        for v, pad in ((0, 14), (1, 15)):
+        for v, pad in ((0, 14 - HEAD_BYTES // 4), (1, 15 - HEAD_BYTES // 4)):
             ins = build(pad)
-            check(ins)
+            head, phase = check(ins)
+            assert (head, phase) == ((56, 0) if v == 0 else (60, 4)), (head, phase)   # the placement round 1 measured
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
         f.write("#define NB_FORCE_LOOP_GROUP %d\n" % GROUP)
@@ -216,7 +260,7 @@ def main():
         clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, STRIDE + 1)] + ["scc", "memory"]
         f.write("#define NB_FORCE_LOOP_F64_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob64))
         f.write("#define NB_FORCE_LOOP_F64_GROUP %d\n" % GROUP_F64)
-    n_valu = len([i for i in build(15) if i.startswith("v_")])
+    n_valu = len([i for i in build(11) if i.startswith("v_")])
     print("wrote %s (%d VALU instructions per iteration of %d bodies + prologue/drain)" % (OUT, n_valu, GROUP))
 
 
