@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Kernel configuration sweep on one GPU: (variant, bodies per lane, source sub-segments) -> G pairs/s from the
 HIP-event time of the force kernels.  One process, interleaved rounds (cdna guide §5.4 rule 24).
-usage: python tools/sweep.py [--n N] [--steps K] [--rounds M] [--configs "smem:4:1,lds:2:4,..."]"""
+usage: python tools/sweep.py [--n N] [--steps K] [--rounds M] [--configs "smem:4:1,lds:2:4,isa1:1:8:0:sum=seq:fuse=0,..."]
+config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked][:blk=K][:fuse=0|1]"""
 import argparse
 import importlib
 import os
@@ -24,10 +25,14 @@ def main():
     import numpy as np
     n = args.n
     if args.configs:
-        cfgs = [tuple(c.split(":")) for c in args.configs.split(",")]
-        cfgs = [(c[0], int(c[1]), int(c[2]), int(c[3]) if len(c) > 3 else 0) for c in cfgs]
+        cfgs = []
+        for c in args.configs.split(","):
+            f = c.split(":")
+            kv = tuple(sorted(x for x in f[3:] if "=" in x))
+            w = [int(x) for x in f[3:] if "=" not in x]
+            cfgs.append((f[0], int(f[1]), int(f[2]), w[0] if w else 0, kv))
     else:
-        cfgs = [(v, r, s, 0) for v in ("smem", "lds") for r in (1, 2, 4) for s in (1, 2, 4, 8)]
+        cfgs = [(v, r, s, 0, ()) for v in ("smem", "lds") for r in (1, 2, 4) for s in (1, 2, 4, 8)]
     pos, vel = nb.make_bodies(n, dtype=np.float64 if args.fp64 else np.float32)
     eng = nb.NBody(n, fp64=args.fp64, tile=args.tile)
     eng.set_option(nb.OPT_TIMING, 1)
@@ -35,7 +40,11 @@ def main():
     res = {c: [] for c in cfgs}
     for rnd in range(args.rounds):
         for c in cfgs:
-            v, r, s, w = c
+            v, r, s, w, kv = c
+            opts = dict(x.split("=") for x in kv)
+            eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_SEQ if opts.get("sum", "blocked") == "seq" else nb.SUM_BLOCKED)
+            eng.set_option(nb.OPT_SUM_BLOCK, int(opts.get("blk", 1024)))
+            eng.set_option(nb.OPT_FUSE_COMBINE, int(opts.get("fuse", 1)))
             eng.set_option(nb.OPT_WAVES_PER_SIMD, w)
             eng.set_option(nb.OPT_VARIANT, vmap[v])
             eng.set_option(nb.OPT_ISA_PHASE, int(v[3:]) if v.startswith("isa") else 0)
@@ -52,8 +61,8 @@ def main():
     bound = 256 * 4 * 64 / 30 * 2.4
     print("# n=%d steps=%d rounds=%d; issue bound %.0f G/s at 2.4 GHz" % (n, args.steps, args.rounds, bound))
     for c in sorted(cfgs, key=lambda c: -max(res[c])):
-        print("%-9s R=%d jsub=%-3d waves/SIMD<=%d  best %7.1f  median %7.1f G pairs/s  (%.1f %% of issue bound)"
-              % (c[0], c[1], c[2], c[3] or 8, max(res[c]), sorted(res[c])[len(res[c]) // 2], 100 * max(res[c]) / bound), flush=True)
+        print("%-9s R=%d jsub=%-3d waves/SIMD<=%d %-24s best %7.1f  median %7.1f G pairs/s  (%.1f %% of issue bound)"
+              % (c[0], c[1], c[2], c[3] or 8, " ".join(c[4]), max(res[c]), sorted(res[c])[len(res[c]) // 2], 100 * max(res[c]) / bound), flush=True)
     eng.close()
 
 
