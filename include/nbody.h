@@ -59,8 +59,11 @@ enum {
                               arrived slices (default); 2 = one launch per arriving slice, each released by that slice's
                               event; 0 = gather first, one launch */
   NBODY_OPT_SUM_BLOCK = 13, /* NBODY_SUM_BLOCKED: sources per level-1 block (multiple of 64; default 1024) */
-  NBODY_OPT_FUSE_COMBINE = 14, /* 1 (default): the segments' partial sums are added by the last workgroup to arrive, inside
-                              the force launch (one launch per step); 0: a separate combine kernel (same bits) */
+  NBODY_OPT_ISA_LONG_BUFFERS = 15, /* NBODY_VARIANT_ISA: scalar buffers of 8 bodies instead of 4 (-1 = auto: when a launch has fewer
+                              than 32 workgroups per CU; 0, 1 = force).  Same bits either way. */
+  NBODY_OPT_FUSE_COMBINE = 14, /* 1: the segments' partial sums are added by the last wave to arrive, inside the force launch (one
+                              launch per step); 0: a separate combine kernel; -1 (default): one launch when the launch has
+                              >= 4 workgroups per CU, where the hand-off hides behind other workgroups, else two.  Same bits. */
   NBODY_OPT_GRAPH = 12,    /* 1 (default): nbody_step on one GPU replays a HIP graph of two steps; 0: launch every kernel */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
   NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: 1 = the product loop (default), 0 = the same instructions placed one 4-byte

@@ -7,7 +7,7 @@
 //                             rank's slice of pos[cur^1]; the other slices of pos[cur^1] arrive over xGMI
 //   vel      n_local words    never leaves the rank
 //   partial  nseg x n_local   per-source-segment partial forces (unused when nseg == 1)
-//   tickets  1 per 256 rows   arrival counters of the in-launch combine (zero between steps)
+//   tickets  4 per 256 rows   arrival counters (one per wave) of the in-launch combine (zero between steps)
 //   force    n_local words    last combined forces (mailbox / parity entry points)
 // word = {x,y,z,w}: 16 B (fp32) or 32 B (fp64) — the reference's RAM word, S/top_level.vhd:206-208.
 //
@@ -84,7 +84,7 @@ struct Local {
   void* vel = nullptr;
   void* partial = nullptr;
   size_t partial_words = 0;            // capacity of `partial`
-  unsigned* tickets = nullptr;         // one arrival counter per block of 256 rows
+  unsigned* tickets = nullptr;         // arrival counters: one per wave of every block of 256 rows
   void* force = nullptr;
   void* full_scratch = nullptr;        // N words: all-gather of a sharded array for the host (multi-process)
   int cur = 0;
@@ -101,8 +101,8 @@ struct Local {
 
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
-  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_BLOCKED, sum_block = 1024, fuse = 1;
-  int timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1;
+  int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_BLOCKED, sum_block = 1024, fuse = -1;
+  int timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1, long_buffers = -1;
 };
 
 // what happens to the force of a row once all its segments are summed
@@ -125,7 +125,7 @@ struct Global {
   Local loc[kMaxLocal];
   Options opt;
   // resolved launch configuration
-  int variant = NBODY_VARIANT_SMEM, R = 4, sub = 1, nslices = 1, nseg = 1;
+  int variant = NBODY_VARIANT_SMEM, R = 4, sub = 1, nslices = 1, nseg = 1, fuse = 1;
   int cu_count = 0, clock_khz = 0;
   long long steps_done = 0;
 };
@@ -165,12 +165,23 @@ void resolve_config() {
     int b = blocks_for(n_local, R);
     sub = (target_blocks + b - 1) / b;
     int slice_len = g.n / g.nslices;
-    int max_sub = std::max(1, slice_len / 256);    // keep >= 256 sources per segment (a wave walks its segment serially)
+    int max_sub = std::max(1, slice_len / 128);    // keep >= 128 sources per segment (a wave walks its segment serially)
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
   }
   g.sub = sub;
   g.nseg = g.nslices * g.sub;
+  // One launch per step (the last-arriving wave adds the partial sums) or two (combine_kernel)?  Same bits.  Measured
+  // (profiles/r02_small_n.md): the in-launch hand-off costs every workgroup a store drain and an atomic round trip
+  // (~3 us) and the last arriver nseg/8 rounds of loads; a kernel boundary plus the combine kernel cost ~7 us per step.
+  // With >= 4 workgroups per CU the hand-offs hide behind other workgroups (N >= 16384: one launch is level or ahead);
+  // below that they are exposed (N = 4096: 16 us per step in two launches, 20-23 in one).
+  const int cus = g.cu_count > 0 ? g.cu_count : 256;
+  const long long wgs = (long long)blocks_for(n_local, R) * (g.nslices > 1 ? g.sub : g.nseg);
+  g.fuse = g.opt.fuse < 0 ? (wgs >= 4LL * cus ? 1 : 0) : g.opt.fuse;
 }
+
+// arrival counters: one per wave (4) of every block of 256 rows, padded to a multiple of 16 bytes
+size_t ticket_words(const Local& L) { return ((size_t)blocks_for(L.n_local, 1) * 4 + 63) / 64 * 64; }
 
 int alloc_local(Local& L) {
   HIPC(hipSetDevice(L.device));
@@ -181,7 +192,7 @@ int alloc_local(Local& L) {
   for (int b = 0; b < 2; ++b) { HIPC(hipMalloc(&L.pos[b], (g.n + pad) * wb)); HIPC(hipMemset(L.pos[b], 0, (g.n + pad) * wb)); }
   HIPC(hipMalloc(&L.vel, (L.n_local + pad) * wb));
   HIPC(hipMalloc(&L.force, (L.n_local + pad) * wb));
-  const size_t nt = (size_t)blocks_for(L.n_local, 1) + 16;
+  const size_t nt = ticket_words(L);
   HIPC(hipMalloc((void**)&L.tickets, nt * sizeof(unsigned)));
   HIPC(hipMemset(L.tickets, 0, nt * sizeof(unsigned)));
   HIPC(hipMemset(L.vel, 0, (L.n_local + pad) * wb));
@@ -208,9 +219,9 @@ void drop_step_graph() {
 }
 
 int reconfigure() {
-  const int o_variant = g.variant, o_R = g.R, o_sub = g.sub, o_nsl = g.nslices;
+  const int o_variant = g.variant, o_R = g.R, o_sub = g.sub, o_nsl = g.nslices, o_fuse = g.fuse;
   resolve_config();
-  const bool changed = o_variant != g.variant || o_R != g.R || o_sub != g.sub || o_nsl != g.nslices;
+  const bool changed = o_variant != g.variant || o_R != g.R || o_sub != g.sub || o_nsl != g.nslices || o_fuse != g.fuse;
   if (changed) drop_step_graph();
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
@@ -219,7 +230,7 @@ int reconfigure() {
       // the arrival counters are zero between steps by construction (the last arriver resets its own); a change of
       // the row-block shape is the one moment to re-zero them all (stream-ordered with the kernels that use them).
       HIPC(hipSetDevice(L.device));
-      HIPC(hipMemsetAsync(L.tickets, 0, ((size_t)blocks_for(L.n_local, 1) + 16) * sizeof(unsigned), L.compute));
+      HIPC(hipMemsetAsync(L.tickets, 0, ticket_words(L) * sizeof(unsigned), L.compute));
     }
   }
   return NBODY_OK;
@@ -292,7 +303,7 @@ int launch_f32_R(Local& L, dim3 grid, const ForceArgs& a) {
 }
 
 // how a launch finishes its rows: directly (one segment), by the last-arriving workgroup, or by combine_kernel
-inline int finish_mode() { return g.nseg == 1 ? kFinishDirect : (g.opt.fuse ? kFinishLast : kFinishStore); }
+inline int finish_mode() { return g.nseg == 1 ? kFinishDirect : (g.fuse ? kFinishLast : kFinishStore); }
 
 void fill_args(Local& L, ForceArgs& a, int row0, int row_count, const Finish& fin, float dt, double dt64) {
   memset(&a, 0, sizeof(a));
@@ -323,6 +334,10 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   a.slice_start = slice_start;
   const int R = g.R;
   dim3 grid(blocks_for(row_count, R), nsl * g.sub, 1);
+  // few workgroups per CU = few waves per SIMD and short segments: the scalar loads are no longer hidden by other waves
+  const int cus = g.cu_count > 0 ? g.cu_count : 256;
+  // (measured at N = 16384, 16 workgroups per CU: +4 % with the long buffers; N = 65536, 64 per CU: -2 %)
+  a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y < 32LL * cus ? 1 : 0) : g.opt.long_buffers;
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
     return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f64<0>, grid, a) : launch_timed(L, force_isa_f64<1>, grid, a);
   }
@@ -343,7 +358,8 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
     }
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
-    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0>, grid, a) : launch_timed(L, force_isa_f32<1>, grid, a);
+    if (a.long_buffers) return launch_timed(L, force_isa_f32<1, 1>, grid, a);
+    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0, 0>, grid, a) : launch_timed(L, force_isa_f32<1, 0>, grid, a);
   }
   switch (R) {
     case 1: return launch_f32_R<1>(L, grid, a);
@@ -959,7 +975,8 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_ARITH: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.arith = value; break;
     case NBODY_OPT_SUM_ORDER: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.sum_order = value; break;
     case NBODY_OPT_SUM_BLOCK: if (value < 8 || value > (1 << 24) || value % 64) return NBODY_ERR_ARG; g.opt.sum_block = value; break;
-    case NBODY_OPT_FUSE_COMBINE: g.opt.fuse = value ? 1 : 0; break;
+    case NBODY_OPT_FUSE_COMBINE: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.fuse = value; break;
+    case NBODY_OPT_ISA_LONG_BUFFERS: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.long_buffers = value; break;
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
     case NBODY_OPT_COMM: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;

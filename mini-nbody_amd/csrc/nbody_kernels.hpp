@@ -60,7 +60,7 @@ struct ForceArgs {
   void* vel;            // [n_rows]
   void* pos_next_rows;  // [n_rows]
   void* force_out;      // [n_rows] {Fx,Fy,Fz,0} (S/compute_store.vhd:242) or null
-  unsigned* tickets;    // one counter per block of rows (kFinishLast), zero between steps
+  unsigned* tickets;    // four counters per block of rows, one per wave (kFinishLast); zero between steps
   int n_src;            // N
   int n_rows;           // bodies owned by this rank
   int row0;             // first row handled by this launch (nbody_forces_rows)
@@ -71,6 +71,7 @@ struct ForceArgs {
   int finish;           // kFinish*
   int do_kick, do_drift;  // what to do with the finished force: v += dt*F, then r' = r + v*dt
   int sum_block;        // K sources per level-1 block; 0 = one sequential sum per segment
+  int long_buffers;     // ISA variant: 8-body scalar buffers (launches with < 4 waves per SIMD, see tools/gen_force_loop.py)
   int fpga16;           // 1: S/fxyz.vhd:129-184 + S/final_adder.vhd:88-104 summation order inside a segment
   float dt;
   double dt64;
@@ -258,13 +259,13 @@ __device__ __forceinline__ V4 load_word_sc1(__amdgpu_buffer_rsrc_t rs, int off) 
 // Finish the R rows of a lane (rows lane_row + r*kBlock, valid below row_end) given the segment's sums.
 //   kFinishDirect  apply them.
 //   kFinishStore   store them as this segment's partial; combine_kernel adds the segments later.
-//   kFinishLast    the split-reduction hand-off inside one launch: every workgroup stores its partial with write-through
-//                  stores, every storing wave drains them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane
-//                  takes a ticket with an agent-scope atomic add; the workgroup whose ticket is the last of the row block's
-//                  nseg (over all launches of the step) learns that from the returned value, acquires at agent scope,
-//                  and its lanes read the nseg partials of their rows with sc1 loads IN ASCENDING SEGMENT ORDER — so the
-//                  result is the same whichever workgroup arrives last — then apply them and zero the ticket for the
-//                  next step.  Workgroups of one row block share blockIdx.x; nothing waits on another workgroup.
+//   kFinishLast    the split-reduction hand-off inside one launch, wave by wave (no workgroup barrier: the four waves of a
+//                  workgroup own disjoint rows).  Every wave stores its partial sums with write-through (sc1) stores, drains
+//                  them (s_waitcnt vmcnt(0)), and ONE lane takes a ticket with an agent-scope atomic add on the counter of
+//                  (row block, wave).  The wave whose ticket is the last of the nseg (over all launches of the step) learns
+//                  that from the returned value, and its lanes read the nseg partials of their rows with sc1 loads IN
+//                  ASCENDING SEGMENT ORDER — so the result is the same whichever wave arrives last — apply them and zero
+//                  the ticket for the next step.  Nothing ever waits on another wave.
 //
 // The arguments are re-read here from the kernel-argument segment (every force kernel takes one ForceArgs by value, at
 // offset 0 of it) instead of being kept in SGPRs through the source loop, where the two scalar-load buffers of the
@@ -291,7 +292,7 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
     }
     return;
   }
-  __shared__ int s_last;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg_row0 = a.row0 + blockIdx.x * (kBlock * R);            // wave-uniform: first row of this workgroup
   const int wg_rows = min(kBlock * R, row_end - wg_row0);
   const int lane_off = (int)(threadIdx.x * sizeof(V4));
@@ -304,21 +305,19 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
       store_word_sc1<V4>(rs, lane_off + r * kBlock * (int)sizeof(V4), o);   // rows past row_end fall outside the descriptor: dropped
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(a.tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == (unsigned)(a.nseg - 1));
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached memory before its ticket is taken
+  unsigned* ticket = a.tickets + (size_t)blockIdx.x * 4 + wave;
+  unsigned t = 0;
+  if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+  if (t != (unsigned)(a.nseg - 1)) return;
+  // The partials are read with sc1 loads only (they bypass this CU's L1, the one cache another wave's stores never
+  // refresh), which is what makes them visible; the agent-scope acquire is issued as well (it completes in the
+  // background: the loads below do not depend on it).
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   T fx[R], fy[R], fz[R];
-  constexpr int C = R >= 4 ? 2 : (R == 2 ? 4 : 8);   // partials in flight per row (loads first, then the adds in order)
+  constexpr int C = R >= 4 ? 2 : (R == 2 ? 4 : 8);   // partials in flight per row (loads first, then the adds in order); 16 would cost
+                                                      // the hand-scheduled kernel its 7th and 8th resident wave (79 VGPRs), which small N needs
   for (int sg0 = 0; sg0 < a.nseg; sg0 += C) {
     V4 p[C][R];
 #pragma unroll
@@ -346,7 +345,7 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
     const int i = lane_row + r * kBlock;
     if (i < row_end) apply_force<T, V4>(a, i, me[r], fx[r], fy[r], fz[r]);
   }
-  if (threadIdx.x == 0) __hip_atomic_store(a.tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void block_segment(const ForceArgs& a, int* seg, int* jb, int* je) {
@@ -427,15 +426,25 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
 // explains the hardware facts it is built on).  One body per lane; same arithmetic, same order (blocks of
 // sum_block sources folded into the level-2 accumulators inside the loop) and hence the same bits as
 // force_smem_f32<1, 0>.  PLACEMENT = 1 is the product loop, 0 the same instructions one 4-byte phase off (kept to
-// re-measure the code-placement effect).
+// re-measure the code-placement effect).  LONG = 1: scalar buffers of 8 bodies for launches with few waves per SIMD
+// (small N), where a 4-body buffer's 48 instructions no longer cover the ~280 ns of a scalar load.
 #include "force_loop_gfx950.inc"
-template <int PLACEMENT>
+template <int PLACEMENT, int LONG>
 __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const float eps = soft_f32();
   const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
+  const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
+  const int count = je - jb;
+  // Touch the scalar-cache lines of the segment's first sources now, so that they travel together with the row load:
+  // the loop's own first s_load is issued only after the wait for xi, yi, zi (one memory latency saved per wave,
+  // which is what a short segment at small N feels).
+  // (one dword each, unconditional: jb + 4 stays inside the arrays' 64-word pad; no branch and no register reuse, so
+  //  hipcc has no reason to wait for them before the row load)
+  const NB_CONST float* srcw = (const NB_CONST float*)(uintptr_t)a.src;
+  const float warm0 = srcw[4 * (size_t)jb], warm1 = srcw[4 * (size_t)jb + 16];
   f4 me[1];
   load_rows<float, f4, 1>(a, i, row_end, me);
   const float xi = me[0].x, yi = me[0].y, zi = me[0].z;
@@ -443,14 +452,19 @@ __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
   s.clear();
   float ax = 0.0f, ay = 0.0f, az = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
   int j = jb;
-  const int count = je - jb;
-  const int groups = count / NB_FORCE_LOOP_GROUP;
+  constexpr int group = LONG ? NB_FORCE_LOOP_LONG_GROUP : NB_FORCE_LOOP_GROUP;
+  const int groups = count / group;
   const bool blocked = a.sum_block > 0;
   // groups per block: sum_block is a multiple of the group (nbody_set_option); sequential = one block never finished
-  const int blk = blocked ? a.sum_block / NB_FORCE_LOOP_GROUP : 0x7fffffff;
+  const int blk = blocked ? a.sum_block / group : 0x7fffffff;
   if (groups > 0) {
     const uint64_t p = (uint64_t)(uintptr_t)a.src + (uint64_t)jb * sizeof(f4);
-    if constexpr (PLACEMENT == 1) {
+    if constexpr (LONG) {   // its own kernel: the 64 buffer SGPRs would cost the product loop its 8th resident wave
+      asm volatile(NB_FORCE_LOOP_LONG
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
+                   : NB_FORCE_LOOP_LONG_CLOBBERS);
+    } else if constexpr (PLACEMENT == 1) {
       asm volatile(NB_FORCE_LOOP_V1
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
                    : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
@@ -461,11 +475,11 @@ __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
                    : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
                    : NB_FORCE_LOOP_CLOBBERS);
     }
-    j += groups * NB_FORCE_LOOP_GROUP;
+    j += groups * group;
   }
-  // the (< 8) sources left over, with the compiled pair function: identical operations.  They belong to the last,
-  // unfinished block (sum_block is a multiple of 8, so a block never ends inside them).
-  const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
+  asm volatile("" :: "s"(warm0), "s"(warm1));   // the warm-up loads must not be dropped as dead
+  // the (< 8 or < 16) sources left over, with the compiled pair function: identical operations.  They belong to the
+  // last, unfinished block (sum_block is a multiple of 64, so a block never ends inside them).
   for (; j < je; ++j) {
     f4 q = src[j];
     pair_f32<0>(q.x, q.y, q.z, xi, yi, zi, eps, ax, ay, az);

@@ -27,7 +27,7 @@ def test_c_host_program_matches_oracle(nb, oracle_fast, extra):
     cfg = re.search(r"(\d+) segments, sum block (\d+), (\d+) launch", out.stdout)
     assert cfg, out.stdout
     segments, block, launches = (int(cfg.group(k)) for k in (1, 2, 3))
-    assert block == 1024 and launches == 1 and segments > 1      # the engine's own configuration
+    assert block == 1024 and launches in (1, 2) and segments > 1      # the engine's own configuration
     pos, vel = nb.make_bodies(n)
     oracle_fast.step_order(pos, vel, 0.01, iters, summ=O.SUM_BLOCKED, block=block, sub=segments)
     want = pos[:, :3].astype(np.float64).sum(0)
@@ -43,7 +43,7 @@ def test_gpu_host_program_and_cpu_program_print_the_same_checksum():
     assert os.path.exists(cpu) and os.path.exists(EXE)
     line = lambda out: [l for l in out.splitlines() if l.startswith("checksum")][0]
     for cpu_args, gpu_args in (([], ["--sum", "seq", "--jsub", "1"]),
-                               (["--sum", "blocked", "--segments", "16"], ["--jsub", "16"]),
+                               (["--sum", "blocked", "--segments", "16"], ["--jsub", "16", "--one-launch"]),
                                (["--sum", "blocked", "--block", "256", "--segments", "3"], ["--jsub", "3", "--block", "256", "--two-launch"])):
         a = subprocess.run([cpu, "4096", "10"] + cpu_args, capture_output=True, text=True, timeout=300)
         b = subprocess.run([EXE, "4096", "10", "--strict"] + gpu_args, capture_output=True, text=True, timeout=300)

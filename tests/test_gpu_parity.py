@@ -83,6 +83,10 @@ def test_defaults_are_the_timed_configuration(nb, engine_factory):
     cfg = eng.config
     assert cfg["variant"] == "isa" and cfg["iblock"] == 1 and cfg["sum_order"] == "blocked" and cfg["sum_block"] == 1024
     assert cfg["launches_per_step"] == 1 and cfg["nseg"] > 1          # several segments, still one launch per step
+    small = engine_factory(4096)                                      # few workgroups per CU: the hand-off would be exposed
+    assert small.config["launches_per_step"] == 2 and small.config["variant"] == "isa"
+    small.set_option(nb.OPT_FUSE_COMBINE, 1)
+    assert small.config["launches_per_step"] == 1
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 257, 1000, 1024, 1025, 2085, 5000])
@@ -168,13 +172,16 @@ def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engin
     assert np.all(ref[:, 3] == 0)   # S/compute_store.vhd:242: the 4th word is 0
 
 
-@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 100, 1031, 1024, 2047, 2056, 3000])
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 31, 33, 100, 1031, 1024, 2047, 2056, 3000])
 @pytest.mark.parametrize("summ", ["blocked", "seq"])
-def test_isa_loop_equals_compiled_kernel_ragged(nb, engine_factory, n, summ):
-    """Default (hand-scheduled ISA loop, groups of 8 sources + scalar tail, block folds inside the loop) vs the
-    hipcc-scheduled kernel: same bits — forces and three steps, one segment and the auto segmentation."""
+@pytest.mark.parametrize("long_buffers", [0, 1])
+def test_isa_loop_equals_compiled_kernel_ragged(nb, engine_factory, n, summ, long_buffers):
+    """Default (hand-scheduled ISA loop, groups of 8 sources + scalar tail, block folds inside the loop; and its
+    long-buffer form for launches with few waves per SIMD, groups of 16) vs the hipcc-scheduled kernel: same bits —
+    forces and three steps, one segment and the auto segmentation."""
     pos, vel = nb.make_bodies(n, seed=100 + n)
     eng = engine_factory(n)
+    eng.set_option(nb.OPT_ISA_LONG_BUFFERS, long_buffers)
     eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED if summ == "blocked" else nb.SUM_SEQ)
     eng.set_option(nb.OPT_SUM_BLOCK, 64)            # several blocks even at these sizes
     for jsub in (1, 0):

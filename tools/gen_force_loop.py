@@ -81,55 +81,72 @@ BX, BY, BZ = "v15", "v16", "v17"        # level-2 accumulators (finished blocks)
 TOT, BLK, FULL = 72, 73, 74             # groups still to do after this block, groups per block, "this block is a full one"
 HEAD_BYTES = 16                         # the four 4-byte scalar instructions between the label `2:` and the loop head
 
+# register maps: the product loop (two 4-body buffers) and the long-buffer loop (two 8-body buffers)
+SHORT = dict(bodies=4, a=A_BASE, b=B_BASE, ptr=PTR, cnt=CNT, stride=STRIDE, tot=TOT, blk=BLK, full=FULL)
+LONG = dict(bodies=8, a=36, b=68, ptr=28, cnt=35, stride=33, tot=31, blk=30, full=27)   # s32, s100, s101 are reserved by hipcc
+GROUP_LONG = 16
 
-def build(pad):
+
+def loads(m, base, first_byte):
+    """s_load_dwordx16 instructions filling the buffer at SGPR `base` from PTR + first_byte"""
+    return ["s_load_dwordx16 s[%d:%d], s[%d:%d], 0x%x" % (base + 16 * k, base + 16 * k + 15, m["ptr"], m["ptr"] + 1, first_byte + 64 * k)
+            for k in range(m["bodies"] // 4)]
+
+
+def build(pad, m=SHORT):
     """pad: s_nop count after .p2align 6, so that the inner loop's head `1:` sits 4*pad + HEAD_BYTES bytes past a
-    64-byte line (60 for the product loop: every VALU instruction of the loop then starts at 4 mod 8 bytes)."""
+    64-byte line (60 for the product loop: every VALU instruction of the loop then starts at 4 mod 8 bytes).
+    m: register map.  SHORT = the product loop: buffers of 4 bodies, a buffer's load is in flight for the 48 VALU
+    instructions of the other one — hidden when >= 4 waves share the SIMD.  LONG = buffers of 8 bodies (two loads each):
+    scalar loads return out of order, so a wave can only wait for ALL of them (lgkmcnt(0)) and the prefetch distance is one
+    buffer; with 1-2 waves per SIMD (small N) a 4-body buffer is computed in ~100 ns against ~280 ns of load latency
+    (measured: 71 ns per source), an 8-body buffer in ~200 ns per wave."""
     px, py, pz = DSETS[1]
+    nb = m["bodies"]
+    buf_bytes = 16 * nb
     ins = [
         "v_mov_b32 %s, %%[xi]" % XI, "v_mov_b32 %s, %%[yi]" % YI, "v_mov_b32 %s, %%[zi]" % ZI,
         "v_mov_b32 %s, %%[ax]" % AX, "v_mov_b32 %s, %%[ay]" % AY, "v_mov_b32 %s, %%[az]" % AZ,
         "v_mov_b32 %s, %%[bx]" % BX, "v_mov_b32 %s, %%[by]" % BY, "v_mov_b32 %s, %%[bz]" % BZ,
         "s_mov_b32 %s, %%[eps]" % EPS,
-        "s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1),
-        "s_mov_b32 s%d, %%[groups]" % TOT,
-        "s_mov_b32 s%d, %%[blk]" % BLK,
-        "s_movk_i32 s%d, 0x80" % STRIDE,
-        "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1),
-    ]
+        "s_mov_b64 s[%d:%d], %%[p]" % (m["ptr"], m["ptr"] + 1),
+        "s_mov_b32 s%d, %%[groups]" % m["tot"],
+        "s_mov_b32 s%d, %%[blk]" % m["blk"],
+        "s_movk_i32 s%d, 0x%x" % (m["stride"], 2 * buf_bytes),
+    ] + loads(m, m["a"], 0)
     # "previous body" of the very first body: d = 0 and inv3 = 0, so fma(0, 0, acc) leaves acc as it is
     ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
     ins.append(".p2align 6")
     ins += ["s_nop 0"] * pad
     # ---- one block of the two-level sum: CNT = min(groups left, groups per block) iterations of the inner loop
     ins.append("2:")
-    ins += ["s_min_u32 s%d, s%d, s%d" % (CNT, TOT, BLK),
-            "s_cmp_eq_u32 s%d, s%d" % (CNT, BLK),
-            "s_cselect_b32 s%d, 1, 0" % FULL,
-            "s_sub_u32 s%d, s%d, s%d" % (TOT, TOT, CNT)]
+    ins += ["s_min_u32 s%d, s%d, s%d" % (m["cnt"], m["tot"], m["blk"]),
+            "s_cmp_eq_u32 s%d, s%d" % (m["cnt"], m["blk"]),
+            "s_cselect_b32 s%d, 1, 0" % m["full"],
+            "s_sub_u32 s%d, s%d, s%d" % (m["tot"], m["tot"], m["cnt"])]
     ins.append("1:")
-    ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
-    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
-    for b in range(4):
-        ins += body(b, A_BASE, b)
-    ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+    ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (m["cnt"], m["cnt"])]
+    ins += loads(m, m["b"], buf_bytes)
+    for b in range(nb):
+        ins += body(b, m["a"], b)
+    ins += ["s_add_u32 s%d, s%d, s%d" % (m["ptr"], m["ptr"], m["stride"]), "s_addc_u32 s%d, s%d, 0" % (m["ptr"] + 1, m["ptr"] + 1)]
     ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
-    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
-    for b in range(4):
-        ins += body(4 + b, B_BASE, b)
-    ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b"]
-    # the block's last body has not been accumulated yet (body 7: d set 1, t register 1)
+    ins += loads(m, m["a"], 0)
+    for b in range(nb):
+        ins += body(nb + b, m["b"], b)
+    ins += ["s_cmp_lg_u32 s%d, 0" % m["cnt"], "s_cbranch_scc1 1b"]
+    # the block's last body has not been accumulated yet (an odd body index: d set 1, t register 1)
     ins += ["v_fma_f32 %s, v%d, v%d, %s" % (AX, px, T2[1], AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, T2[1], AY),
             "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, T2[1], AZ)]
     # a block that stopped short of BLK groups is the segment's last one: its sum stays in level 1 (the caller adds
-    # the < 8 leftover sources to it and folds it)
-    ins += ["s_cmp_eq_u32 s%d, 0" % FULL, "s_cbranch_scc1 3f"]
+    # the leftover sources to it and folds it)
+    ins += ["s_cmp_eq_u32 s%d, 0" % m["full"], "s_cbranch_scc1 3f"]
     # fold: level 2 += level 1 (ascending block order), level 1 = 0, and again no "previous body"
     ins += ["v_add_f32_e64 %s, %s, %s" % (BX, BX, AX), "v_add_f32_e64 %s, %s, %s" % (BY, BY, AY),
             "v_add_f32_e64 %s, %s, %s" % (BZ, BZ, AZ)]
     ins += ["v_mov_b32 %s, 0" % r for r in (AX, AY, AZ)]
     ins += ["v_mov_b32 v%d, 0" % r for r in (px, py, pz, T2[1])]
-    ins += ["s_cmp_lg_u32 s%d, 0" % TOT, "s_cbranch_scc1 2b"]
+    ins += ["s_cmp_lg_u32 s%d, 0" % m["tot"], "s_cbranch_scc1 2b"]
     ins.append("3:")
     # retire the unused prefetch; sums out
     ins += ["s_waitcnt lgkmcnt(0)", "v_mov_b32 %%[ax], %s" % AX, "v_mov_b32 %%[ay], %s" % AY, "v_mov_b32 %%[az], %s" % AZ,
@@ -255,6 +272,13 @@ def main():
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
         f.write("#define NB_FORCE_LOOP_GROUP %d\n" % GROUP)
+        ins = build(15 - HEAD_BYTES // 4, LONG)
+        assert check(ins) == (60, 4)
+        f.write("#define NB_FORCE_LOOP_LONG \"%s\"\n" % "\\n\\t".join(ins))
+        sregs = sorted(set(list(range(LONG["a"], LONG["a"] + 64)) + [LONG["ptr"], LONG["ptr"] + 1] + [LONG[k] for k in ("cnt", "stride", "tot", "blk", "full")]))
+        clob_long = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in sregs] + ["scc", "memory"]
+        f.write("#define NB_FORCE_LOOP_LONG_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob_long))
+        f.write("#define NB_FORCE_LOOP_LONG_GROUP %d\n" % GROUP_LONG)
         for v, pad in ((0, 14), (1, 15)):
             f.write("#define NB_FORCE_LOOP_F64_V%d \"%s\"\n" % (v, "\\n\\t".join(build_f64(pad))))
         clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, STRIDE + 1)] + ["scc", "memory"]
