@@ -155,29 +155,29 @@ void resolve_config() {
   if (g.fp64 && R > 4) R = 4;
   if (g.opt.sum_order == NBODY_SUM_FPGA16 && !g.fp64) R = 1;
   g.R = R;
+  // Small launches and large ones want different things (profiles/r02_small_n.md, one process, wall clock per step):
+  //   large (even 64 segments give >= 16 workgroups per CU; N >= 16384 on one GPU): many short segments for load
+  //     balance over the 256 CUs — 128 workgroups per CU in the launch, up to 64 segments of >= 128 sources (N = 65536:
+  //     64 segments 4547 G/s, 8: 3981; N = 1M: 8 segments 4688, 4: 4660) — and the partial sums added inside the launch
+  //     by the last wave to arrive (one launch per step): its store drain and atomic round trip hide behind other
+  //     workgroups.  Several GPUs: the launch over the rank's OWN slice alone already has 16 per CU.
+  //   small: the step is latency, not issue: ~2 workgroups per CU (N = 4096: 32 segments 16.0 us per step, 16: 18.4,
+  //     64: 19.4; N = 8192: 16 segments 27.2, 64: 31.8) and the sums added by a second small kernel — in one launch the
+  //     hand-off is exposed (N = 4096: 22.7 us, N = 8192: 36.4).
+  const int cus = g.cu_count > 0 ? g.cu_count : 256;
+  const int blocks = blocks_for(n_local, R);
+  const bool small = (long long)blocks * 64 < 16LL * cus;
   int sub = g.opt.jsub;
   if (sub == 0) {
-    const int cus = g.cu_count > 0 ? g.cu_count : 256;
-    // one GPU: 128 workgroups per CU in the launch (N = 65536: 64 segments 4547 G/s, 32: 4466, 16: 4310, 8: 3981;
-    // N = 1M: 8 segments 4688, 4: 4660 — profiles/r01_sweep_isa.txt); several GPUs: the launch over the rank's OWN
-    // slice alone (which runs while the other slices travel) already has 16 per CU
-    const int target_blocks = (g.nslices > 1 ? 16 : 128) * cus;
-    int b = blocks_for(n_local, R);
-    sub = (target_blocks + b - 1) / b;
+    const int target_blocks = (small ? 2 : (g.nslices > 1 ? 16 : 128)) * cus;
+    sub = (target_blocks + blocks - 1) / blocks;
     int slice_len = g.n / g.nslices;
     int max_sub = std::max(1, slice_len / 128);    // keep >= 128 sources per segment (a wave walks its segment serially)
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
   }
   g.sub = sub;
   g.nseg = g.nslices * g.sub;
-  // One launch per step (the last-arriving wave adds the partial sums) or two (combine_kernel)?  Same bits.  Measured
-  // (profiles/r02_small_n.md): the in-launch hand-off costs every workgroup a store drain and an atomic round trip
-  // (~3 us) and the last arriver nseg/8 rounds of loads; a kernel boundary plus the combine kernel cost ~7 us per step.
-  // With >= 4 workgroups per CU the hand-offs hide behind other workgroups (N >= 16384: one launch is level or ahead);
-  // below that they are exposed (N = 4096: 16 us per step in two launches, 20-23 in one).
-  const int cus = g.cu_count > 0 ? g.cu_count : 256;
-  const long long wgs = (long long)blocks_for(n_local, R) * (g.nslices > 1 ? g.sub : g.nseg);
-  g.fuse = g.opt.fuse < 0 ? (wgs >= 4LL * cus ? 1 : 0) : g.opt.fuse;
+  g.fuse = g.opt.fuse < 0 ? (small ? 0 : 1) : g.opt.fuse;
 }
 
 // arrival counters: one per wave (4) of every block of 256 rows, padded to a multiple of 16 bytes
