@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile.sh output directory: per-kernel time from the kernel trace, PMC counters of the
-force kernel averaged per launch, and the derived figures DESIGN.md quotes (clock, VALU busy, HBM bytes).
-usage: python tools/parse_prof.py gpurun_out/prof_<tag> [--json profiles/latest_pmc.json]"""
+force kernel averaged per launch, and the derived figures DESIGN.md quotes — clock, cycles per wave-pair (needs no
+assumption: GRBM cycles x SIMDs / wave-pairs), the wave-lifetime breakdown, HBM-side bytes.  Writes the JSON that
+bench.py attaches to a run of the SAME configuration (`config` is taken from the profiled bench.py line).
+usage: python tools/parse_prof.py gpurun_out/prof_<tag> [--json profiles/pmc_<tag>.json]"""
 import csv
 import glob
 import json
@@ -14,15 +16,24 @@ def main():
     d = sys.argv[1]
     out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
     lines = []
+    bench = None
+    try:
+        txt = [l for l in open(os.path.join(d, "bench_trace.json")).read().splitlines() if l.startswith("{")]
+        bench = json.loads(txt[-1])
+    except Exception:
+        pass
     stats = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
     force_avg_ns = None
     force_name = None
     if stats:
-        lines.append("## rocprofv3 --kernel-trace --stats (bench.py, default steps)")
+        lines.append("## rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline ...")
         for r in csv.DictReader(open(stats[0])):
             lines.append("%-70s calls=%-3s avg=%12.3f us  total=%5.2f %%" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
             if "force_" in r["Name"] and force_avg_ns is None:
                 force_avg_ns, force_name = float(r["AverageNs"]), r["Name"]
+    if bench:
+        lines.append("bench.py line of that run: value %.1f %s, ms_per_step %.3f, kernel_ms_avg (HIP events) %.4f, config %s"
+                     % (bench["value"], bench["unit"], bench["ms_per_step"], bench["roofline"]["kernel_ms_avg"], json.dumps(bench["config"]["kernel"])))
     counters = defaultdict(list)
     durs = []
     meta = {}
@@ -31,32 +42,46 @@ def main():
             if "force_" not in r["Kernel_Name"]:
                 continue
             counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            if r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "SQ_WAVES"):
-                durs.append((r["Counter_Name"], float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
+            if r["Counter_Name"] in ("GRBM_GUI_ACTIVE",):
+                durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
             meta = dict(vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"], grid=r["Grid_Size"], wg=r["Workgroup_Size"], kernel=r["Kernel_Name"])
     avg = {k: sum(v) / len(v) for k, v in counters.items()}
     lines.append("")
-    lines.append("## PMC counters of %s, mean per launch (separate --pmc passes)" % meta.get("kernel", "?"))
+    lines.append("## PMC counters of %s, mean per launch (separate --pmc passes, bench.py --steps 2)" % meta.get("kernel", "?"))
     lines.append("launch: grid=%s wg=%s VGPR=%s SGPR=%s LDS=%s" % (meta.get("grid"), meta.get("wg"), meta.get("vgpr"), meta.get("sgpr"), meta.get("lds")))
     for k in sorted(avg):
         lines.append("%-28s %20.1f   (%d launches)" % (k, avg[k], len(counters[k])))
     derived = {}
-    dur_gui = [x for n, x in durs if n == "GRBM_GUI_ACTIVE"]
-    if dur_gui and "GRBM_GUI_ACTIVE" in avg:
-        t = sum(dur_gui) / len(dur_gui) * 1e-9
+    cfg = None
+    wave_pairs = None
+    if bench:
+        k = bench["config"]["kernel"]
+        cfg = {"n": bench["config"]["n_bodies"], "dtype": bench["dtype"], "n_gpus": bench["n_gpus"], "variant": k["variant"], "iblock": k["iblock"],
+               "nseg": k["nseg"], "sum_order": k["sum_order"], "sum_block": k["sum_block"], "launches_per_step": k["launches_per_step"]}
+        wave_pairs = float(k["n_local"]) * bench["config"]["n_bodies"] / 64.0
+    if durs and "GRBM_GUI_ACTIVE" in avg:
+        t = sum(durs) / len(durs) * 1e-9
+        cycles = avg["GRBM_GUI_ACTIVE"] / 8.0            # the counter is summed over the 8 XCDs
         derived["kernel_s_profiled"] = t
-        derived["clock_ghz"] = avg["GRBM_GUI_ACTIVE"] / 8.0 / t / 1e9     # counter is summed over the 8 XCDs
-    if "SQ_BUSY_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
-        # SQ_* cycle counters are in quad-cycles summed over SEs/CUs as rocprofv3 reports them; ratios are unit-free
-        derived["valu_busy_of_wave_cycles"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"] if avg.get("SQ_WAVE_CYCLES") else None
-    if "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
-        # SQ_ACTIVE_INST_VALU: quad-cycles during which a wave has a VALU instruction executing, summed over waves;
-        # a CDNA4 SIMD keeps two wave64 VALU instructions in flight (4 cycles each, 2-cycle issue), so 100 % busy is
-        # 2 x SIMDs x cycles.  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
-        cycles = avg["GRBM_GUI_ACTIVE"] / 8.0
-        derived["valu_busy_frac"] = avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (2.0 * 1024.0 * cycles)
-    if "SQ_INSTS_VALU" in avg and "SQ_WAVES" in avg:
-        derived["valu_insts_per_wave"] = avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]
+        derived["clock_ghz"] = cycles / t / 1e9
+        if wave_pairs:
+            derived["cycles_per_wave_pair"] = cycles * 1024.0 / wave_pairs      # 1024 SIMDs
+    if avg.get("SQ_WAVE_CYCLES"):
+        wc = avg["SQ_WAVE_CYCLES"]
+        # SQ_* cycle counters are in quad-cycles summed over waves; MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES
+        for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA"):
+            if name in avg:
+                derived["wave_lifetime_frac_" + name[3:].lower()] = avg[name] / wc
+        if wave_pairs:
+            derived["wave_cycles_per_wave_pair"] = wc * 4.0 / wave_pairs
+    if wave_pairs:
+        for name, key in (("SQ_INSTS_VALU", "valu_insts_per_wave_pair"), ("SQ_INSTS_SALU", "salu_insts_per_wave_pair"),
+                          ("SQ_INSTS_SMEM", "smem_insts_per_wave_pair"), ("SQ_INSTS_VALU_TRANS_F32", "trans_f32_insts_per_wave_pair"),
+                          ("SQ_INSTS_VALU_TRANS_F64", "trans_f64_insts_per_wave_pair"), ("SQ_IFETCH", "ifetch_per_wave_pair")):
+            if name in avg:
+                derived[key] = avg[name] / wave_pairs
+        if "SQ_THREAD_CYCLES_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
+            derived["thread_cycles_valu_per_wave_pair_div64"] = avg["SQ_THREAD_CYCLES_VALU"] / 64.0 / wave_pairs
     if "FETCH_SIZE" in avg:
         # FETCH_SIZE is in KiB of 64-B requests; gfx950 tallies 128-B requests of wide coalesced reads at 64 B (x2), MI355X_MICROARCH.md §HBM
         derived["fetch_bytes_raw"] = avg["FETCH_SIZE"] * 1024.0
@@ -73,13 +98,16 @@ def main():
     lines.append("")
     lines.append("## derived")
     for k, v in derived.items():
-        lines.append("%-28s %s" % (k, ("%.6g" % v) if isinstance(v, float) else v))
+        lines.append("%-42s %s" % (k, ("%.6g" % v) if isinstance(v, float) else v))
     if force_avg_ns:
-        lines.append("%-28s %.3f ms (%s)" % ("force kernel avg (trace)", force_avg_ns / 1e6, force_name))
+        lines.append("%-42s %.3f ms (%s)" % ("force kernel avg (trace)", force_avg_ns / 1e6, force_name))
     print("\n".join(lines))
     if out_json:
-        json.dump({"source": d, "kernel": meta.get("kernel"), "counters_mean_per_launch": avg, **derived,
-                   "force_kernel_avg_ms_trace": force_avg_ns / 1e6 if force_avg_ns else None}, open(out_json, "w"), indent=1)
+        json.dump({"source": d, "config": cfg, "kernel": meta.get("kernel"), "launch": meta, "counters_mean_per_launch": avg, **derived,
+                   "force_kernel_avg_ms_trace": force_avg_ns / 1e6 if force_avg_ns else None,
+                   "note": "FETCH_SIZE/WRITE_SIZE are L2 memory-side (fabric) request bytes; Infinity-Cache hits are counted too "
+                           "(MI355X_MICROARCH.md §HBM); FETCH_SIZE doubled as that section prescribes for 64-B scalar / 16-B-per-lane reads."},
+                  open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
