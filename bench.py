@@ -61,6 +61,12 @@ def cpu_baseline(n, seed, fp64):
     except Exception:
         path = None
     ora = O.Oracle(fast=True, path=path)
+    # all the cores this process may run on (torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the other
+    # ranks are idle at a barrier while this runs)
+    try:
+        ora.set_num_threads(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
     cores = ora.num_threads()
     nb = importlib.import_module("mini-nbody_amd")
     pos, _ = nb.make_bodies(n, seed=seed, dtype=np.float64 if fp64 else np.float32)

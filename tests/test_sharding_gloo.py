@@ -40,7 +40,8 @@ WORKER = textwrap.dedent("""
                 reqs = [dist.isend(out, (rank + 1) % world), dist.irecv(inc, (rank - 1) % world)]
                 [r.wait() for r in reqs]
                 src[b0:b1] = inc.numpy()
-        acc = S.sharded_forces(rank, world, src, sub, lambda rows, s_: ora.forces_f32(rows, s_))
+        # per-segment force function: the engine's default order inside a segment (blocks of {block} sources, two levels)
+        acc = S.sharded_forces(rank, world, src, sub, lambda rows, s_: ora.forces_order(rows, s_, summ=O.SUM_BLOCKED, block={block}))
         kick = (np.float64(dt) * acc[:, :3].astype(np.float64) + my_vel[:, :3]).astype(np.float32)
         my_vel[:, :3] = kick
         nxt = buf[cur ^ 1]
@@ -61,28 +62,20 @@ def free_port():
     return p
 
 
-def single_process(nb, oracle, n, P, sub, steps):
-    S = nb.sharding
+def single_process(nb, oracle, n, P, sub, steps, block):
+    """the oracle's own statement of the engine's order (ref_step_f32_order): P slices x sub pieces, blocked sums"""
+    import oracle as O
     pos, vel = nb.make_bodies(n, seed=5)
-    dt = np.float32(0.01)
-    for _ in range(steps):
-        parts = []
-        for q in range(P):
-            for t in range(sub):
-                b, e = S.segment_bounds(q, t, n, P, sub)
-                parts.append(oracle.forces_f32(pos, pos[b:e]))
-        acc = S.combine_ascending(parts)
-        vel[:, :3] = (np.float64(dt) * acc[:, :3].astype(np.float64) + vel[:, :3]).astype(np.float32)
-        pos[:, :3] = (vel[:, :3].astype(np.float64) * np.float64(dt) + pos[:, :3]).astype(np.float32)
+    oracle.step_order(pos, vel, 0.01, steps, summ=O.SUM_BLOCKED, block=block, nslices=P, sub=sub)
     return pos, vel
 
 
-@pytest.mark.parametrize("world,n,sub", [(2, 301, 2), (3, 200, 1)])
-def test_gloo_ring_matches_single_process(nb, oracle, tmp_path, world, n, sub):
+@pytest.mark.parametrize("world,n,sub,block", [(2, 301, 2, 64), (3, 200, 1, 1024), (2, 1500, 3, 128)])
+def test_gloo_ring_matches_single_process(nb, oracle, tmp_path, world, n, sub, block):
     steps = 3
     out = str(tmp_path / "r")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, n=n, sub=sub, steps=steps, out=out))
+    script.write_text(WORKER.format(root=ROOT, n=n, sub=sub, steps=steps, out=out, block=block))
     port = free_port()
     procs = []
     for r in range(world):
@@ -92,7 +85,7 @@ def test_gloo_ring_matches_single_process(nb, oracle, tmp_path, world, n, sub):
     for p in procs:
         o, _ = p.communicate(timeout=300)
         assert p.returncode == 0, o.decode()[-3000:]
-    want_p, want_v = single_process(nb, oracle, n, world, sub, steps)
+    want_p, want_v = single_process(nb, oracle, n, world, sub, steps, block)
     got_p = np.concatenate([np.load(out + "_pos%d.npy" % r) for r in range(world)])
     got_v = np.concatenate([np.load(out + "_vel%d.npy" % r) for r in range(world)])
     assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32))
