@@ -160,7 +160,7 @@ void resolve_config() {
   //     balance over the 256 CUs — 128 workgroups per CU in the launch, up to 64 segments of >= 128 sources (N = 65536:
   //     64 segments 4547 G/s, 8: 3981; N = 1M: 8 segments 4688, 4: 4660) — and the partial sums added inside the launch
   //     by the last wave to arrive (one launch per step): its store drain and atomic round trip hide behind other
-  //     workgroups.  Several GPUs: the launch over the rank's OWN slice alone already has 16 per CU.
+  //     workgroups.
   //   small: the step is latency, not issue: ~2 workgroups per CU (N = 4096: 32 segments 16.0 us per step, 16: 18.4,
   //     64: 19.4; N = 8192: 16 segments 27.2, 64: 31.8) and the sums added by a second small kernel — in one launch the
   //     hand-off is exposed (N = 4096: 22.7 us, N = 8192: 36.4).
@@ -169,7 +169,10 @@ void resolve_config() {
   const bool small = (long long)blocks * 64 < 16LL * cus;
   int sub = g.opt.jsub;
   if (sub == 0) {
-    const int target_blocks = (small ? 2 : (g.nslices > 1 ? 16 : 128)) * cus;
+    // workgroups per launch-slice: the step's launches together have 128 (2) per CU whatever the rank count, so that
+    // P GPUs see the same segment length as one (N = 1M: 8 pieces per slice for P = 1, 2, 4, 8; two virtual ranks with
+    // 2 pieces of 262144 sources ran 2.3 % behind one rank, with 8 pieces level)
+    const int target_blocks = std::max(1, (small ? 2 : 128) * cus / g.nslices);
     sub = (target_blocks + blocks - 1) / blocks;
     int slice_len = g.n / g.nslices;
     int max_sub = std::max(1, slice_len / 128);    // keep >= 128 sources per segment (a wave walks its segment serially)

@@ -7,7 +7,7 @@
  * §2: billion pair-interactions/s = N^2 * timed_steps / seconds / 1e9.
  *
  * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]
- *              [--sum seq|blocked] [--block K] [--one-launch | --two-launch] [--long-buffers 0|1]
+ *              [--sum seq|blocked] [--block K] [--one-launch | --two-launch] [--long-buffers 0|1] [--overlap 0|1|2]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -27,7 +27,7 @@ static double now_s(void) {
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s failed: %s\n", #call, nbody_error_string(rc_)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0, sum = -1, block = 0, two_launch = -1, long_buffers = -1;
+  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0, sum = -1, block = 0, two_launch = -1, long_buffers = -1, overlap = -1;
   unsigned long long seed = NBODY_IC_DEFAULT_SEED;
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
@@ -39,12 +39,13 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--strict")) strict = 1;
     else if (!strcmp(argv[a], "--two-launch")) two_launch = 1;
     else if (!strcmp(argv[a], "--one-launch")) two_launch = 0;
+    else if (!strcmp(argv[a], "--overlap") && a + 1 < argc) overlap = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--long-buffers") && a + 1 < argc) long_buffers = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--sum") && a + 1 < argc) { ++a; sum = !strcmp(argv[a], "seq") ? NBODY_SUM_SEQ : NBODY_SUM_BLOCKED; }
     else if (!strcmp(argv[a], "--block") && a + 1 < argc) block = atoi(argv[++a]);
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1] [--overlap 0|1|2]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   const float dt = 0.01f;
@@ -56,6 +57,7 @@ int main(int argc, char **argv) {
   if (block > 0) CHECK(nbody_set_option(NBODY_OPT_SUM_BLOCK, block));
   if (two_launch >= 0) CHECK(nbody_set_option(NBODY_OPT_FUSE_COMBINE, !two_launch));   /* in-launch combine or separate kernel (same bits) */
   if (long_buffers >= 0) CHECK(nbody_set_option(NBODY_OPT_ISA_LONG_BUFFERS, long_buffers));
+  if (overlap >= 0) CHECK(nbody_set_option(NBODY_OPT_OVERLAP, overlap));        /* multi-GPU: 0 gather first, 1 own slice then the rest, 2 per arriving slice */
 
   double total = 0.0;
   if (!fp64) {
