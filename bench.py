@@ -35,6 +35,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL / cross-process device memory on this pool needs dmabuf IPC (the launcher normally exports it already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FLOP_PER_PAIR = 20                # SURVEY.md §8(d) convention (literal count: 18)
 PEAK_VECTOR_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 (32) flop/clk x 2.4 GHz

@@ -176,6 +176,7 @@ void resolve_config() {
     sub = (target_blocks + blocks - 1) / blocks;
     int slice_len = g.n / g.nslices;
     int max_sub = std::max(1, slice_len / 128);    // keep >= 128 sources per segment (a wave walks its segment serially)
+    sub = std::max(sub, (slice_len + 131071) / 131072);   // and <= 131072 sources (a workgroup's lifetime: the launch's tail)
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
   }
   g.sub = sub;
@@ -361,8 +362,8 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
     }
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
-    if (a.long_buffers) return launch_timed(L, force_isa_f32<1, 1>, grid, a);
-    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0, 0>, grid, a) : launch_timed(L, force_isa_f32<1, 0>, grid, a);
+    if (a.long_buffers) return launch_timed(L, force_isa_long_f32, grid, a);
+    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0>, grid, a) : launch_timed(L, force_isa_f32<1>, grid, a);
   }
   switch (R) {
     case 1: return launch_f32_R<1>(L, grid, a);

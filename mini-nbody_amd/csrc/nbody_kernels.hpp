@@ -429,8 +429,11 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
 // re-measure the code-placement effect).  LONG = 1: scalar buffers of 8 bodies for launches with few waves per SIMD
 // (small N), where a 4-body buffer's 48 instructions no longer cover the ~280 ns of a scalar load.
 #include "force_loop_gfx950.inc"
+// SGPR budgets: 81-96 SGPRs leave room for 7 waves per SIMD, <= 80 for 8 (MI355X_MICROARCH.md, "Occupancy API" row).  The
+// product loop's scalars end at s72 (79 with VCC etc.: 8 waves); the long-buffer loop holds 64 buffer SGPRs (106: 6 waves),
+// which is why it is a kernel of its own.
 template <int PLACEMENT, int LONG>
-__global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
+__device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
   int seg, jb, je;
   block_segment(a, &seg, &jb, &je);
   const float eps = soft_f32();
@@ -488,6 +491,9 @@ __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) {
   s.close(blocked, blocked && (count % a.sum_block) != 0);
   finish_rows<float, f4, 1>(seg, i, row_end, me, s);
 }
+template <int PLACEMENT>
+__global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) { force_isa_f32_body<PLACEMENT, 0>(a); }
+__global__ void __launch_bounds__(kBlock) force_isa_long_f32(ForceArgs a) { force_isa_f32_body<1, 1>(a); }
 
 // ---------------------------------------------------------------------------
 // LDS variant (the north_star's "source bodies tiled into LDS", tile = 256 by

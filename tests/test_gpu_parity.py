@@ -241,6 +241,19 @@ def test_one_launch_combine_equals_combine_kernel(nb, engine_factory):
                 out[fuse] = (f,) + (p1, v1) + eng.download()
             for x, y in zip(out[1], out[0]):
                 assert np.array_equal(bits(x), bits(y)), (n, variant, iblock, jsub, jsl)
+    # a long run under load (many resident workgroups per CU, thousands of hand-offs per step, partial buffers and
+    # tickets reused every step): any stale or torn read of a partial sum changes the final bits
+    for n, steps in ((20000, 3000), (65536 + 77, 300)):
+        pos, vel = nb.make_bodies(n, seed=7)
+        eng = engine_factory(n)
+        out = {}
+        for fuse in (1, 0):
+            eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+            eng.upload(pos, vel)
+            eng.step(1e-4, steps)
+            out[fuse] = eng.download()
+        assert eng.config["nseg"] == 64
+        assert np.array_equal(bits(out[1][0]), bits(out[0][0])) and np.array_equal(bits(out[1][1]), bits(out[0][1])), n
     # fp64 words (two 16-byte stores per partial)
     n = 5000
     pos, vel = nb.make_bodies(n, seed=2, dtype=np.float64)

@@ -15,7 +15,7 @@ profiles/r01_sweep_isa.txt):
         sub sub sub | fma fma fma | rsq | 3 accumulating fma of the PREVIOUS body | mul mul
     — the previous body's accumulates are the wait state, and this was the fastest legal single-chain order in the
     stream harness (ord_defA, 2.63 cycles/instruction).
-  * live-in / live-out values are copied into fixed registers (v8-v14, s34) so that the loop's bytes, banks and
+  * live-in / live-out values are copied into fixed registers (v8-v17, s33) so that the loop's bytes, banks and
     placement do not depend on hipcc's register allocation around the asm statement; the loop head sits 60 bytes
     past a 64-byte line.
   * a single fp32 accumulator per axis is off by 1e-4 of the force after 2^20 terms; the reference keeps 16 partial
@@ -49,9 +49,10 @@ OUT = os.path.join(ROOT, "mini-nbody_amd", "csrc", "force_loop_gfx950.inc")
 U = 22                                  # inv^2 (even)
 T2 = [20, 24]                           # d2 / inv / inv3 (even), alternating with the body index
 DSETS = [(21, 23, 25), (27, 29, 31)]    # dx dy dz (odd), alternating with the body index
-XI, YI, ZI, AX, AY, AZ, EPS = "v8", "v9", "v10", "v12", "v13", "v14", "s34"
-A_BASE, B_BASE = 36, 52
-PTR, CNT, STRIDE = 68, 70, 71
+XI, YI, ZI, AX, AY, AZ, EPS = "v8", "v9", "v10", "v12", "v13", "v14", "s33"
+A_BASE, B_BASE = 36, 52            # s_load_dwordx16 destinations: multiples of 4
+PTR, CNT, STRIDE = 34, 68, 69      # highest SGPR of the loop: s72 -> 79 SGPRs with VCC etc.: 8 waves per SIMD fit
+                                   # (81-96 SGPRs: 7, MI355X_MICROARCH.md "Occupancy API" row)
 GROUP = 8
 
 
@@ -78,12 +79,12 @@ def body(k, sbase, b):
 
 
 BX, BY, BZ = "v15", "v16", "v17"        # level-2 accumulators (finished blocks)
-TOT, BLK, FULL = 72, 73, 74             # groups still to do after this block, groups per block, "this block is a full one"
+TOT, BLK, FULL = 70, 71, 72             # groups still to do after this block, groups per block, "this block is a full one"
 HEAD_BYTES = 16                         # the four 4-byte scalar instructions between the label `2:` and the loop head
 
 # register maps: the product loop (two 4-body buffers) and the long-buffer loop (two 8-body buffers)
 SHORT = dict(bodies=4, a=A_BASE, b=B_BASE, ptr=PTR, cnt=CNT, stride=STRIDE, tot=TOT, blk=BLK, full=FULL)
-LONG = dict(bodies=8, a=36, b=68, ptr=28, cnt=35, stride=33, tot=31, blk=30, full=27)   # s32, s100, s101 are reserved by hipcc
+LONG = dict(bodies=8, a=36, b=68, ptr=28, cnt=35, stride=34, tot=31, blk=30, full=27)   # s32, s100, s101 are reserved by hipcc
 GROUP_LONG = 16
 
 
@@ -199,31 +200,34 @@ def body_f64(k, sbase, b):
     return out
 
 
+F64_PTR, F64_CNT, F64_STRIDE = 68, 70, 71    # the fp64 loop keeps its own scalars (it is VGPR-limited to 5 waves anyway)
+
+
 def build_f64(pad):
     px, py, pz = D_DSETS[1]
     ins = [
         "v_mov_b64 %s, %%[xi]" % vp(D_XI), "v_mov_b64 %s, %%[yi]" % vp(D_YI), "v_mov_b64 %s, %%[zi]" % vp(D_ZI),
         "v_mov_b64 %s, %%[ax]" % vp(D_AX), "v_mov_b64 %s, %%[ay]" % vp(D_AY), "v_mov_b64 %s, %%[az]" % vp(D_AZ),
         "s_mov_b64 %s, %%[eps]" % sp(D_EPS),
-        "s_mov_b64 s[%d:%d], %%[p]" % (PTR, PTR + 1),
-        "s_mov_b32 s%d, %%[groups]" % CNT,
-        "s_movk_i32 s%d, 0x80" % STRIDE,
-        "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1),
+        "s_mov_b64 s[%d:%d], %%[p]" % (F64_PTR, F64_PTR + 1),
+        "s_mov_b32 s%d, %%[groups]" % F64_CNT,
+        "s_movk_i32 s%d, 0x80" % F64_STRIDE,
+        "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, F64_PTR, F64_PTR + 1),
     ]
     ins += ["v_mov_b64 %s, 0" % vp(r) for r in (px, py, pz, D_Y[1])]
     ins.append(".p2align 6")
     ins += ["s_nop 0"] * pad
     ins.append("1:")
-    ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (CNT, CNT)]
-    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, PTR, PTR + 1))
+    ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (F64_CNT, F64_CNT)]
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, F64_PTR, F64_PTR + 1))
     for b in range(2):
         ins += body_f64(b, A_BASE, b)
-    ins += ["s_add_u32 s%d, s%d, s%d" % (PTR, PTR, STRIDE), "s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1)]
+    ins += ["s_add_u32 s%d, s%d, s%d" % (F64_PTR, F64_PTR, F64_STRIDE), "s_addc_u32 s%d, s%d, 0" % (F64_PTR + 1, F64_PTR + 1)]
     ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
-    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, PTR, PTR + 1))
+    ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, F64_PTR, F64_PTR + 1))
     for b in range(2):
         ins += body_f64(2 + b, B_BASE, b)
-    ins += ["s_cmp_lg_u32 s%d, 0" % CNT, "s_cbranch_scc1 1b"]
+    ins += ["s_cmp_lg_u32 s%d, 0" % F64_CNT, "s_cbranch_scc1 1b"]
     ins += ["v_fma_f64 %s, %s, %s, %s" % (vp(D_AX), vp(px), vp(D_Y[1]), vp(D_AX)),
             "v_fma_f64 %s, %s, %s, %s" % (vp(D_AY), vp(py), vp(D_Y[1]), vp(D_AY)),
             "v_fma_f64 %s, %s, %s, %s" % (vp(D_AZ), vp(pz), vp(D_Y[1]), vp(D_AZ))]
@@ -262,7 +266,7 @@ def check(ins):
 
 def main():
     regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ, BX, BY, BZ)]))
-    clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(A_BASE, FULL + 1)] + ["scc", "memory"]
+    clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(PTR, FULL + 1)] + ["scc", "memory"]
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_force_loop.py — do not edit.  See that file for the why.\n")
         for v, pad in ((0, 14 - HEAD_BYTES // 4), (1, 15 - HEAD_BYTES // 4)):
@@ -281,7 +285,7 @@ def main():
         f.write("#define NB_FORCE_LOOP_LONG_GROUP %d\n" % GROUP_LONG)
         for v, pad in ((0, 14), (1, 15)):
             f.write("#define NB_FORCE_LOOP_F64_V%d \"%s\"\n" % (v, "\\n\\t".join(build_f64(pad))))
-        clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, STRIDE + 1)] + ["scc", "memory"]
+        clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, F64_STRIDE + 1)] + ["scc", "memory"]
         f.write("#define NB_FORCE_LOOP_F64_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob64))
         f.write("#define NB_FORCE_LOOP_F64_GROUP %d\n" % GROUP_F64)
     n_valu = len([i for i in build(11) if i.startswith("v_")])
