@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--sum-block", type=int, default=0)
     ap.add_argument("--fuse", type=int, default=-1, help="1: one launch per step (in-launch combine), 0: two, -1: auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", choices=["auto", "ring", "allgather"], default="auto")
+    ap.add_argument("--comm", choices=["auto", "ring", "allgather", "direct"], default="auto")
     ap.add_argument("--transport", choices=["auto", "rccl", "host"], default="auto")
     ap.add_argument("--overlap", type=int, default=1, help="0 gather first, 1 own slice then the rest, 2 one launch per arriving slice")
     args = ap.parse_args()
@@ -177,7 +177,7 @@ def main():
     if args.sum_block > 0:
         eng.set_option(nb.OPT_SUM_BLOCK, args.sum_block)
     eng.set_option(nb.OPT_FUSE_COMBINE, args.fuse)
-    eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER}[args.comm])
+    eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER, "direct": nb.COMM_DIRECT}[args.comm])
     eng.set_option(nb.OPT_OVERLAP, args.overlap)
     import numpy as np
     pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)

@@ -89,7 +89,8 @@ enum { NBODY_SUM_SEQ = 0,          /* one accumulator per segment, sources ascen
                                       fp64 contexts always sum sequentially. */ };
 enum { NBODY_COMM_RING = 0,        /* P-1 ncclSend/ncclRecv ring steps, one event per arriving slice */
        NBODY_COMM_ALLGATHER = 1,   /* one in-place ncclAllGather (needs N divisible by the rank count, else ring) */
-       NBODY_COMM_AUTO = 2         /* default: RING (the north_star's form) */ };
+       NBODY_COMM_AUTO = 2,        /* default: RING (the north_star's form) */
+       NBODY_COMM_DIRECT = 3       /* one group of P-1 sends of the own slice and P-1 receives: one hop over all xGMI links */ };
 
 /* ---- info keys (nbody_get_info) ---- */
 enum { NBODY_INFO_N = 1, NBODY_INFO_N_LOCAL, NBODY_INFO_FIRST_BODY, NBODY_INFO_RANK, NBODY_INFO_NRANKS,

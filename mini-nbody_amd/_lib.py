@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libnbody_hip.so")
 VARIANT_AUTO, VARIANT_SMEM, VARIANT_LDS, VARIANT_READLANE, VARIANT_ISA = range(5)
 ARITH_FMA3, ARITH_REFERENCE, ARITH_STRICT, ARITH_REFERENCE_STRICT = 0, 1, 2, 3
 SUM_SEQ, SUM_FPGA16, SUM_BLOCKED = 0, 1, 2
-COMM_RING, COMM_ALLGATHER, COMM_AUTO = 0, 1, 2
+COMM_RING, COMM_ALLGATHER, COMM_AUTO, COMM_DIRECT = 0, 1, 2, 3
 (INFO_N, INFO_N_LOCAL, INFO_FIRST_BODY, INFO_RANK, INFO_NRANKS, INFO_VARIANT, INFO_IBLOCK, INFO_JSUB, INFO_NSEG,
  INFO_DEVICE, INFO_CU_COUNT, INFO_CLOCK_KHZ, INFO_FP64, INFO_TILE, INFO_STEPS_DONE, INFO_SUM_ORDER, INFO_SUM_BLOCK,
  INFO_LAUNCHES_PER_STEP, INFO_HAS_COMM) = range(1, 20)

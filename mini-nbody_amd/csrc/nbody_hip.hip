@@ -431,6 +431,20 @@ int rccl_gather(Local& L, void* dev_full, hipEvent_t* ev) {
     if (ev) for (int s = 1; s < P; ++s) HIPC(hipEventRecord(ev[s], L.comm));
     return NBODY_OK;
   }
+  if (g.opt.comm == NBODY_COMM_DIRECT) {
+    // fully connected: the own slice goes straight to every peer and every peer's slice comes straight back, all in one
+    // RCCL group — one hop over the 7 xGMI links at once instead of P-1 ring hops
+    NCCLC(g_rccl.GroupStart());
+    for (int s = 1; s < P; ++s) {
+      const int to = (L.rank + s) % P, from = ring_slice(L.rank, s);
+      const int fr = slice_first(from, g.n, P), lr = slice_first(from + 1, g.n, P) - fr;
+      NCCLC(g_rccl.Send(word_ptr(dev_full, L.first), (size_t)L.n_local * wb, ncclChar, to, L.comm_h, L.comm));
+      NCCLC(g_rccl.Recv(word_ptr(dev_full, fr), (size_t)lr * wb, ncclChar, from, L.comm_h, L.comm));
+    }
+    NCCLC(g_rccl.GroupEnd());
+    if (ev) for (int s = 1; s < P; ++s) HIPC(hipEventRecord(ev[s], L.comm));
+    return NBODY_OK;
+  }
   for (int s = 1; s < P; ++s) {
     const int qs = ring_slice(L.rank, s - 1);   // forward what arrived last (own slice at s = 1)
     const int qr = ring_slice(L.rank, s);
@@ -982,7 +996,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_FUSE_COMBINE: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.fuse = value; break;
     case NBODY_OPT_ISA_LONG_BUFFERS: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.long_buffers = value; break;
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
-    case NBODY_OPT_COMM: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.comm = value; break;
+    case NBODY_OPT_COMM: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;
     case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;

@@ -38,6 +38,12 @@ def ring_schedule(rank, nranks):
     return [(s, ring_slice(rank, s - 1, nranks), ring_slice(rank, s, nranks)) for s in range(1, nranks)]
 
 
+def direct_schedule(rank, nranks):
+    """[(send_to, recv_from)] of the fully connected form (NBODY_COMM_DIRECT): one group, the own slice to every peer,
+    every peer's own slice back; pair s of rank r matches pair s of rank recv_from (who sends to r)."""
+    return [((rank + s) % nranks, (rank - s) % nranks) for s in range(1, nranks)]
+
+
 def combine_ascending(partials):
     """((p0 + p1) + p2) + ... in the dtype of the partials (combine_kernel in nbody_kernels.hpp)."""
     acc = partials[0].copy()

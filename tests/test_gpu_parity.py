@@ -790,7 +790,7 @@ def test_rccl_calls_on_a_one_rank_communicator(nb, engine_factory):
     assert len(uid) == 128 and any(uid)
     eng = engine_factory(n, rank=0, nranks=1, uid=uid)
     assert eng.info(nb._lib.INFO_HAS_COMM) == 1
-    for comm in (nb.COMM_RING, nb.COMM_ALLGATHER, nb.COMM_AUTO):
+    for comm in (nb.COMM_RING, nb.COMM_ALLGATHER, nb.COMM_AUTO, nb.COMM_DIRECT):
         eng.set_option(nb.OPT_COMM, comm)
         moved = eng.comm_selftest()
         assert moved == (n // 2) * 16            # one rank: the all-gather moves nothing, the ring step half the array

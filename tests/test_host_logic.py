@@ -57,6 +57,17 @@ def test_ring_schedule(nb):
     assert all(have[r] == set(range(P)) for r in range(P))
 
 
+def test_direct_schedule(nb):
+    S = nb.sharding
+    for P in (2, 3, 8):
+        for r in range(P):
+            sched = S.direct_schedule(r, P)
+            assert sorted(f for _, f in sched) == sorted(set(range(P)) - {r})     # every other slice arrives once
+            for s, (to, frm) in enumerate(sched):
+                assert S.direct_schedule(frm, P)[s][0] == r                        # the sender's matching send targets r
+                assert S.direct_schedule(to, P)[s][1] == r
+
+
 def test_sharded_forces_any_arrival_order(nb, oracle):
     """Partials combined in ascending source order do not depend on the order of arrival."""
     pos, _ = nb.make_bodies(600, seed=3)
