@@ -18,7 +18,11 @@
  * by no reference fixture: at that level parity is "unpinned" in the sense of
  * the task statement, and is anchored on (i) the stage KATs above, (ii) an
  * independent fp64 evaluation, (iii) a pure-Python/numpy restatement
- * (tests/test_oracle_vs_numpy.py).
+ * (tests/test_oracle_vs_numpy.py), (iv) whole-pipeline known answers computed
+ * by a third, exact-rational Python statement of the arithmetic and of the
+ * summation orders (tests/golden/make_system.py -> system_*.json), which this
+ * oracle and the HIP engine (strict arithmetic) both reproduce bit for bit
+ * (tests/test_golden_system.py).
  */
 #ifndef NBODY_REF_H
 #define NBODY_REF_H

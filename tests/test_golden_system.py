@@ -1,0 +1,112 @@
+"""Whole-pipeline known answers (tests/golden/system_*.json, made by tests/golden/make_system.py: a pure-Python
+exact-rational statement of the arithmetic and of the engine's summation order that shares no code with the C oracle
+or the HIP kernels).  On CPU the oracle must reproduce them bit for bit; on the GPU the engine in strict arithmetic
+must — with no oracle in the loop."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "system_*.json")))
+
+
+def words(hexlist):
+    return np.array([int(h, 16) for h in hexlist], np.uint32).view(np.float32).reshape(-1, 4)
+
+
+def load(path):
+    fx = json.load(open(path))
+    fx["dt"] = float(np.array([int(fx["dt_bits"], 16)], np.uint32).view(np.float32)[0])
+    for k in ("pos0", "vel0", "forces0", "pos", "vel"):
+        fx[k] = words(fx[k])
+    return fx
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_fixtures_present():
+    assert len(FIXTURES) >= 3
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_inputs_are_the_seeded_generator(nb, path):
+    fx = load(path)
+    pos, vel = nb.make_bodies(fx["n"], seed=fx["seed"])
+    assert np.array_equal(bits(pos), bits(fx["pos0"])) and np.array_equal(bits(vel), bits(fx["vel0"]))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_oracle_reproduces_the_fixture(oracle, oracle_fast, path):
+    fx = load(path)
+    o = fx["order"]
+    for ora in (oracle, oracle_fast):
+        order = O.order(summ=O.SUM_BLOCKED if o["summ"] == "blocked" else O.SUM_SEQ, block=o["block"] or 1024,
+                        nslices=o["nslices"], sub=o["sub"])
+        f = ora.forces_order(fx["pos0"], order_=order)
+        assert np.array_equal(bits(f), bits(fx["forces0"]))
+        p, v = fx["pos0"].copy(), fx["vel0"].copy()
+        ora.step_order(p, v, fx["dt"], fx["steps"], order_=order)
+        assert np.array_equal(bits(p), bits(fx["pos"])) and np.array_equal(bits(v), bits(fx["vel"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_engine_reproduces_the_fixture(nb, path):
+    """strict arithmetic, the fixture's order, every delivery variant and both combine forms; then the device loop"""
+    fx = load(path)
+    o = fx["order"]
+    eng = nb.NBody(fx["n"])
+    try:
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED if o["summ"] == "blocked" else nb.SUM_SEQ)
+        if o["block"]:
+            eng.set_option(nb.OPT_SUM_BLOCK, o["block"])
+        eng.set_option(nb.OPT_JSLICES, o["nslices"])
+        eng.set_option(nb.OPT_JSUB, o["sub"])
+        for variant, iblock in ((nb.VARIANT_SMEM, 1), (nb.VARIANT_SMEM, 4), (nb.VARIANT_LDS, 2), (nb.VARIANT_READLANE, 2)):
+            for fuse in (1, 0):
+                eng.set_option(nb.OPT_VARIANT, variant)
+                eng.set_option(nb.OPT_IBLOCK, iblock)
+                eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+                assert np.array_equal(bits(eng.forces(fx["pos0"])), bits(fx["forces0"])), (variant, iblock, fuse)
+                eng.upload(fx["pos0"], fx["vel0"])
+                eng.step(fx["dt"], fx["steps"])
+                p, v = eng.download()
+                assert np.array_equal(bits(p), bits(fx["pos"])) and np.array_equal(bits(v), bits(fx["vel"])), (variant, iblock, fuse)
+        # host-pointer bodyForce()/integrate()
+        p, v = fx["pos0"].copy(), fx["vel0"].copy()
+        for _ in range(fx["steps"]):
+            eng.bodyForce(p, v, fx["dt"])
+            eng.integrate(p, v, fx["dt"])
+        assert np.array_equal(bits(p), bits(fx["pos"])) and np.array_equal(bits(v), bits(fx["vel"]))
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_virtual_ranks_reproduce_the_sharded_fixture(nb, monkeypatch):
+    """system_n150_sharded.json is the order of a 4-rank job (4 slices x 2 pieces): 4 virtual ranks on this GPU must give it"""
+    monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
+    fx = load(os.path.join(HERE, "golden", "system_n150_sharded.json"))
+    o = fx["order"]
+    for overlap in (1, 2, 0):
+        eng = nb.NBody(fx["n"], ngpus=o["nslices"])
+        try:
+            eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+            eng.set_option(nb.OPT_SUM_BLOCK, o["block"])
+            eng.set_option(nb.OPT_JSUB, o["sub"])
+            eng.set_option(nb.OPT_OVERLAP, overlap)
+            assert np.array_equal(bits(eng.forces(fx["pos0"])), bits(fx["forces0"]))
+            eng.upload(fx["pos0"], fx["vel0"])
+            eng.step(fx["dt"], fx["steps"])
+            p, v = eng.download()
+            assert np.array_equal(bits(p), bits(fx["pos"])) and np.array_equal(bits(v), bits(fx["vel"])), overlap
+        finally:
+            eng.close()
