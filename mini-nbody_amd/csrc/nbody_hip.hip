@@ -497,9 +497,14 @@ int enqueue_step(float dt, double dt64) {
   const Finish fin = {true, true, false};
   const bool need_gather = !g.loc[0].all_present;
   if (need_gather && g.opt.overlap) {
-    // own slice first: these kernels run while the other slices travel (second stream / host-staged exchange)
+    // The own-slice kernels run while the other slices travel on the second stream.  Device-side transports (RCCL,
+    // peer copies) are enqueued FIRST: they only wait for the previous step's end, and their small kernels/copies get
+    // onto the device ahead of the force launch that fills every CU; the host-staged exchange blocks the host, so
+    // there the force launch goes first.
+    const bool host_staged = g.multiprocess && g.host_gather;
+    if (!host_staged) NBC(enqueue_gather(g.loc[0].cur));
     for (int l = 0; l < g.nlocal; ++l) NBC(launch_force(g.loc[l], 0, g.loc[l].n_local, g.loc[l].rank, 1, fin, dt, dt64));
-    NBC(enqueue_gather(g.loc[0].cur));
+    if (host_staged) NBC(enqueue_gather(g.loc[0].cur));
   }
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
