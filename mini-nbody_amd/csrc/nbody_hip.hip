@@ -363,6 +363,7 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
     if (a.long_buffers) return launch_timed(L, force_isa_long_f32, grid, a);
+    if (g.opt.isa_phase == 2) return launch_timed(L, force_isa_f32<2>, grid, a);
     return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0>, grid, a) : launch_timed(L, force_isa_f32<1>, grid, a);
   }
   switch (R) {
@@ -1005,7 +1006,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;
     case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
-    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 1) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
+    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); drop_step_graph(); return reconfigure(); }

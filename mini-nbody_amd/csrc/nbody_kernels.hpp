@@ -467,6 +467,11 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
                    : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
                    : NB_FORCE_LOOP_LONG_CLOBBERS);
+    } else if constexpr (PLACEMENT == 2) {   // experiment: staggered s_load_dwordx8 delivery
+      asm volatile(NB_FORCE_LOOP_V2
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
+                   : NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 1) {
       asm volatile(NB_FORCE_LOOP_V1
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)

@@ -94,7 +94,12 @@ def loads(m, base, first_byte):
             for k in range(m["bodies"] // 4)]
 
 
-def build(pad, m=SHORT):
+def half_loads(m, base, first_byte):
+    """the same 64 bytes as one s_load_dwordx16, as two s_load_dwordx8 (experiment: staggered delivery)"""
+    return ["s_load_dwordx8 s[%d:%d], s[%d:%d], 0x%x" % (base + 8 * k, base + 8 * k + 7, m["ptr"], m["ptr"] + 1, first_byte + 32 * k) for k in range(2)]
+
+
+def build(pad, m=SHORT, stagger=False):
     """pad: s_nop count after .p2align 6, so that the inner loop's head `1:` sits 4*pad + HEAD_BYTES bytes past a
     64-byte line (60 for the product loop: every VALU instruction of the loop then starts at 4 mod 8 bytes).
     m: register map.  SHORT = the product loop: buffers of 4 bodies, a buffer's load is in flight for the 48 VALU
@@ -127,14 +132,32 @@ def build(pad, m=SHORT):
             "s_sub_u32 s%d, s%d, s%d" % (m["tot"], m["tot"], m["cnt"])]
     ins.append("1:")
     ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (m["cnt"], m["cnt"])]
-    ins += loads(m, m["b"], buf_bytes)
-    for b in range(nb):
-        ins += body(b, m["a"], b)
+    if stagger:
+        # experiment: the other buffer arrives as two s_load_dwordx8, the second one issued two
+        # bodies later, so that the returning data is written to the SGPR file in two bursts instead of one
+        lb = half_loads(m, m["b"], buf_bytes)
+        ins.append(lb[0])
+        for b in range(nb):
+            ins += body(b, m["a"], b)
+            if b == 1:
+                ins.append(lb[1])
+    else:
+        ins += loads(m, m["b"], buf_bytes)
+        for b in range(nb):
+            ins += body(b, m["a"], b)
     ins += ["s_add_u32 s%d, s%d, s%d" % (m["ptr"], m["ptr"], m["stride"]), "s_addc_u32 s%d, s%d, 0" % (m["ptr"] + 1, m["ptr"] + 1)]
     ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
-    ins += loads(m, m["a"], 0)
-    for b in range(nb):
-        ins += body(nb + b, m["b"], b)
+    if stagger:
+        la = half_loads(m, m["a"], 0)
+        ins.append(la[0])
+        for b in range(nb):
+            ins += body(nb + b, m["b"], b)
+            if b == 1:
+                ins.append(la[1])
+    else:
+        ins += loads(m, m["a"], 0)
+        for b in range(nb):
+            ins += body(nb + b, m["b"], b)
     ins += ["s_cmp_lg_u32 s%d, 0" % m["cnt"], "s_cbranch_scc1 1b"]
     # the block's last body has not been accumulated yet (an odd body index: d set 1, t register 1)
     ins += ["v_fma_f32 %s, v%d, v%d, %s" % (AX, px, T2[1], AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, T2[1], AY),
@@ -276,6 +299,9 @@ def main():
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
         f.write("#define NB_FORCE_LOOP_GROUP %d\n" % GROUP)
+        ins = build(15 - HEAD_BYTES // 4, SHORT, stagger=True)
+        assert check(ins) == (60, 4)
+        f.write("#define NB_FORCE_LOOP_V2 \"%s\"\n" % "\\n\\t".join(ins))
         ins = build(15 - HEAD_BYTES // 4, LONG)
         assert check(ins) == (60, 4)
         f.write("#define NB_FORCE_LOOP_LONG \"%s\"\n" % "\\n\\t".join(ins))

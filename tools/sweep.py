@@ -38,7 +38,7 @@ def main():
     eng = nb.NBody(n, fp64=args.fp64, tile=args.tile)
     eng.set_option(nb.OPT_TIMING, 0 if args.wall else 1)
     import time
-    vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, "isa0": nb.VARIANT_ISA, "isa1": nb.VARIANT_ISA}
+    vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, "isa0": nb.VARIANT_ISA, "isa1": nb.VARIANT_ISA, "isa2": nb.VARIANT_ISA}
     res = {c: [] for c in cfgs}
     for rnd in range(args.rounds):
         for c in cfgs:
