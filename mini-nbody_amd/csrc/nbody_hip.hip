@@ -363,7 +363,23 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
     if (a.long_buffers) return launch_timed(L, force_isa_long_f32, grid, a);
-    if (g.opt.isa_phase == 2) return launch_timed(L, force_isa_f32<2>, grid, a);
+    switch (g.opt.isa_phase) {
+      case 2: return launch_timed(L, force_isa_f32<2>, grid, a);
+      case 3: return launch_timed(L, force_isa_f32<3>, grid, a);   // 3..5: timing-only diagnostics, wrong results
+      case 4: return launch_timed(L, force_isa_f32<4>, grid, a);
+      case 5: return launch_timed(L, force_isa_f32<5>, grid, a);
+      case 6: return launch_timed(L, force_isa_f32<6>, grid, a);
+      case 7: return launch_timed(L, force_isa_f32<7>, grid, a);
+      case 8: return launch_timed(L, force_isa_f32<8>, grid, a);
+      case 9: return launch_timed(L, force_isa_f32<9>, grid, a);    // 9..13: correct loops, other encodings (experiments)
+      case 10: return launch_timed(L, force_isa_f32<10>, grid, a);
+      case 11: return launch_timed(L, force_isa_f32<11>, grid, a);
+      case 12: return launch_timed(L, force_isa_f32<12>, grid, a);
+      case 13: return launch_timed(L, force_isa_f32<13>, grid, a);
+      case 14: return launch_timed(L, force_isa_f32<14>, grid, a);   // 14, 15: timing-only diagnostics, wrong results
+      case 15: return launch_timed(L, force_isa_f32<15>, grid, a);
+      default: break;
+    }
     return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0>, grid, a) : launch_timed(L, force_isa_f32<1>, grid, a);
   }
   switch (R) {
@@ -1006,7 +1022,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;
     case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
-    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
+    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 15) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); drop_step_graph(); return reconfigure(); }

@@ -467,6 +467,41 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
                    : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
                    : NB_FORCE_LOOP_LONG_CLOBBERS);
+#define NB_DIAG_LOOP(TEXT)                                                                                              \
+      asm volatile(TEXT                                                                                                  \
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)            \
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk) \
+                   : NB_FORCE_LOOP_CLOBBERS)
+    } else if constexpr (PLACEMENT == 3) {   // TIMING-ONLY diagnostic forms (wrong results): 3 no transcendental,
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V3);
+    } else if constexpr (PLACEMENT == 4) {   // 4 no scalar loads,
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V4);
+    } else if constexpr (PLACEMENT == 5) {   // 5 neither
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V5);
+    } else if constexpr (PLACEMENT == 6) {   // 6..8: what limits full-rate issue (tools/gen_force_loop.py diag_body)
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V6);
+    } else if constexpr (PLACEMENT == 7) {
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V7);
+    } else if constexpr (PLACEMENT == 8) {
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V8);
+    } else if constexpr (PLACEMENT == 9) {   // 9..13: CORRECT loops with other encodings of the SGPR-reading instructions
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V9);
+    } else if constexpr (PLACEMENT == 10) {
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V10);
+    } else if constexpr (PLACEMENT == 11) {
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V11);
+    } else if constexpr (PLACEMENT == 12) {
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V12);
+    } else if constexpr (PLACEMENT == 13) {
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V13);
+    } else if constexpr (PLACEMENT == 14) {   // 14, 15: TIMING-ONLY (wrong results): VGPR-sourced coordinates with the transcendental, + an LDS read per source
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V14);
+    } else if constexpr (PLACEMENT == 15) {
+      __shared__ f4 diag_tile[64];
+      if (threadIdx.x < 64) diag_tile[threadIdx.x] = me[0];
+      __syncthreads();
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V15);
+#undef NB_DIAG_LOOP
     } else if constexpr (PLACEMENT == 2) {   // experiment: staggered s_load_dwordx8 delivery
       asm volatile(NB_FORCE_LOOP_V2
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)

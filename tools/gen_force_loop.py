@@ -56,12 +56,44 @@ PTR, CNT, STRIDE = 34, 68, 69      # highest SGPR of the loop: s72 -> 79 SGPRs w
 GROUP = 8
 
 
-def body(k, sbase, b):
-    """body k of the group reads source b of the SGPR buffer at sbase; accumulates body k-1"""
+EPSV = "v18"    # eps in a VGPR (even: dz, dz, eps are then not three same-parity reads)
+
+
+def body(k, sbase, b, style="vgpreps"):
+    """body k of the group reads source b of the SGPR buffer at sbase; accumulates body k-1.
+    style: how the instructions that read an SGPR are encoded.  Measured inside the real kernel
+    (profiles/r02_loop_diagnostics.md): a VOP3 (64-bit) instruction with an SGPR source costs ~0.9 cycles more than the
+    same instruction reading VGPRs; the 32-bit VOP2 encoding of v_sub_f32 with the SGPR in src0 costs ~0.2 more.
+      vgpreps every instruction VOP3, source coordinates from SGPRs, eps from a VGPR: THE PRODUCT LOOP (+0.4..1.0 % over e64)
+      e64     every instruction VOP3, source coordinates and eps from SGPRs (round 1's loop; NBODY_OPT_ISA_PHASE 12)
+      e32sub  the three subtractions VOP2 + one s_nop (keeps every 8-byte instruction at 4 mod 8), eps from a VGPR
+      e32sub_nofill  the same without the s_nop (the phase alternates from body to body)
+      e32sub_seps    e32sub with eps still in an SGPR
+      e32all  every instruction that has a 32-bit encoding uses it (phase not controlled)"""
     t, tp = T2[k & 1], T2[(k - 1) & 1]
     dx, dy, dz = DSETS[k & 1]
     px, py, pz = DSETS[(k - 1) & 1]
     s0 = sbase + 4 * b
+    if style != "e64":
+        sub = "v_sub_f32_e64" if style == "vgpreps" else "v_sub_f32_e32"
+        eps = EPS if style == "e32sub_seps" else EPSV
+        out = ["%s v%d, s%d, %s" % (sub, dx, s0, XI), "%s v%d, s%d, %s" % (sub, dy, s0 + 1, YI), "%s v%d, s%d, %s" % (sub, dz, s0 + 2, ZI)]
+        if style in ("e32sub", "e32sub_seps"):
+            out.append("s_nop 0")
+        out.append("v_fma_f32 v%d, v%d, v%d, %s" % (t, dz, dz, eps))
+        if style == "e32all":
+            out += ["v_fmac_f32_e32 v%d, v%d, v%d" % (t, dy, dy), "v_fmac_f32_e32 v%d, v%d, v%d" % (t, dx, dx),
+                    "v_rsq_f32_e32 v%d, v%d" % (t, t),
+                    "v_fmac_f32_e32 %s, v%d, v%d" % (AX, px, tp), "v_fmac_f32_e32 %s, v%d, v%d" % (AY, py, tp),
+                    "v_fmac_f32_e32 %s, v%d, v%d" % (AZ, pz, tp),
+                    "v_mul_f32_e32 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e32 v%d, v%d, v%d" % (t, t, U)]
+        else:
+            out += ["v_fma_f32 v%d, v%d, v%d, v%d" % (t, dy, dy, t), "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dx, dx, t),
+                    "v_rsq_f32_e64 v%d, v%d" % (t, t),
+                    "v_fma_f32 %s, v%d, v%d, %s" % (AX, px, tp, AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, tp, AY),
+                    "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, tp, AZ),
+                    "v_mul_f32_e64 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e64 v%d, v%d, v%d" % (t, t, U)]
+        return out
     return [
         "v_sub_f32_e64 v%d, s%d, %s" % (dx, s0, XI),               # S/dxy.vhd:94-95   target - this
         "v_sub_f32_e64 v%d, s%d, %s" % (dy, s0 + 1, YI),           # S/dxy.vhd:97-98
@@ -99,7 +131,61 @@ def half_loads(m, base, first_byte):
     return ["s_load_dwordx8 s[%d:%d], s[%d:%d], 0x%x" % (base + 8 * k, base + 8 * k + 7, m["ptr"], m["ptr"] + 1, first_byte + 32 * k) for k in range(2)]
 
 
-def build(pad, m=SHORT, stagger=False):
+def diagnostic(ins, no_rsq, no_loads):
+    """TIMING-ONLY forms of a loop (wrong results): v_rsq_f32 -> v_mov_b32 of the same registers (same encoding size,
+    same dependency chain, no transcendental), and/or the loop's s_load_dwordx16 -> two s_nop (same bytes, no scalar
+    memory traffic; the prologue's load stays so the SGPRs hold numbers).  They price the transcendental and the
+    scalar side inside the real kernel (profiles/r02_cycles_per_wave_pair.md)."""
+    out = []
+    in_loop = False
+    for i in ins:
+        if i == "2:":
+            in_loop = True
+        if no_rsq and i.startswith("v_rsq_f32_e64"):
+            i = i.replace("v_rsq_f32_e64", "v_mov_b32_e64")
+        if no_loads and in_loop and i.startswith("s_load_dwordx16"):
+            out += ["s_nop 0", "s_nop 0"]
+            continue
+        out.append(i)
+    return out
+
+
+def diag_body(kind, k, sbase, b):
+    """TIMING-ONLY stand-ins for body() (12 full-rate instructions, no transcendental): what limits full-rate issue?
+       indep    12 v_fma_f32 with no dependency between them (distinct destinations)
+       e32      the pair interaction in 32-bit encodings wherever one exists (v_mov instead of v_rsq)
+       vgprsrc  the pair interaction with the source coordinates read from VGPRs instead of SGPRs"""
+    t, tp = T2[k & 1], T2[(k - 1) & 1]
+    dx, dy, dz = DSETS[k & 1]
+    px, py, pz = DSETS[(k - 1) & 1]
+    s0 = sbase + 4 * b
+    if kind == "indep":
+        dst = [20, 21, 22, 23, 24, 25, 27, 29, 31, 12, 13, 14]
+        return ["v_fma_f32 v%d, v8, v9, v%d" % (d, d) for d in dst]
+    if kind == "e32":
+        return [
+            "v_sub_f32_e32 v%d, s%d, %s" % (dx, s0, XI), "v_sub_f32_e32 v%d, s%d, %s" % (dy, s0 + 1, YI),
+            "v_sub_f32_e32 v%d, s%d, %s" % (dz, s0 + 2, ZI),
+            "v_fma_f32 v%d, v%d, v%d, %s" % (t, dz, dz, EPS),
+            "v_fmac_f32_e32 v%d, v%d, v%d" % (t, dy, dy), "v_fmac_f32_e32 v%d, v%d, v%d" % (t, dx, dx),
+            "v_mov_b32_e32 v%d, v%d" % (t, t),
+            "v_fmac_f32_e32 %s, v%d, v%d" % (AX, px, tp), "v_fmac_f32_e32 %s, v%d, v%d" % (AY, py, tp), "v_fmac_f32_e32 %s, v%d, v%d" % (AZ, pz, tp),
+            "v_mul_f32_e32 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e32 v%d, v%d, v%d" % (t, t, U),
+        ]
+    if kind in ("vgprsrc", "vgprsrc_rsq", "vgprsrc_rsq_lds"):
+        out = body(k, sbase, b, "vgpreps")
+        out[0] = "v_sub_f32_e64 v%d, v16, %s" % (dx, XI)     # v15..v17 hold the level-2 sums: any numbers will do here
+        out[1] = "v_sub_f32_e64 v%d, v15, %s" % (dy, YI)
+        out[2] = "v_sub_f32_e64 v%d, v16, %s" % (dz, ZI)
+        if kind == "vgprsrc":
+            out[6] = out[6].replace("v_rsq_f32_e64", "v_mov_b32_e64")
+        if kind == "vgprsrc_rsq_lds":      # + one broadcast LDS read per source into registers nothing reads
+            out.insert(3, "ds_read_b128 v[40:43], v44")
+        return out
+    raise ValueError(kind)
+
+
+def build(pad, m=SHORT, stagger=False, diag=None, style="vgpreps"):
     """pad: s_nop count after .p2align 6, so that the inner loop's head `1:` sits 4*pad + HEAD_BYTES bytes past a
     64-byte line (60 for the product loop: every VALU instruction of the loop then starts at 4 mod 8 bytes).
     m: register map.  SHORT = the product loop: buffers of 4 bodies, a buffer's load is in flight for the 48 VALU
@@ -115,6 +201,8 @@ def build(pad, m=SHORT, stagger=False):
         "v_mov_b32 %s, %%[ax]" % AX, "v_mov_b32 %s, %%[ay]" % AY, "v_mov_b32 %s, %%[az]" % AZ,
         "v_mov_b32 %s, %%[bx]" % BX, "v_mov_b32 %s, %%[by]" % BY, "v_mov_b32 %s, %%[bz]" % BZ,
         "s_mov_b32 %s, %%[eps]" % EPS,
+        "v_mov_b32 %s, %%[eps]" % EPSV,
+        "v_mov_b32 v44, 0",
         "s_mov_b64 s[%d:%d], %%[p]" % (m["ptr"], m["ptr"] + 1),
         "s_mov_b32 s%d, %%[groups]" % m["tot"],
         "s_mov_b32 s%d, %%[blk]" % m["blk"],
@@ -141,10 +229,14 @@ def build(pad, m=SHORT, stagger=False):
             ins += body(b, m["a"], b)
             if b == 1:
                 ins.append(lb[1])
+    elif diag:
+        ins += ["s_nop 0", "s_nop 0"] * (nb // 4)
+        for b in range(nb):
+            ins += diag_body(diag, b, m["a"], b)
     else:
         ins += loads(m, m["b"], buf_bytes)
         for b in range(nb):
-            ins += body(b, m["a"], b)
+            ins += body(b, m["a"], b, style)
     ins += ["s_add_u32 s%d, s%d, s%d" % (m["ptr"], m["ptr"], m["stride"]), "s_addc_u32 s%d, s%d, 0" % (m["ptr"] + 1, m["ptr"] + 1)]
     ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
     if stagger:
@@ -154,10 +246,14 @@ def build(pad, m=SHORT, stagger=False):
             ins += body(nb + b, m["b"], b)
             if b == 1:
                 ins.append(la[1])
+    elif diag:
+        ins += ["s_nop 0", "s_nop 0"] * (nb // 4)
+        for b in range(nb):
+            ins += diag_body(diag, nb + b, m["b"], b)
     else:
         ins += loads(m, m["a"], 0)
         for b in range(nb):
-            ins += body(nb + b, m["b"], b)
+            ins += body(nb + b, m["b"], b, style)
     ins += ["s_cmp_lg_u32 s%d, 0" % m["cnt"], "s_cbranch_scc1 1b"]
     # the block's last body has not been accumulated yet (an odd body index: d set 1, t register 1)
     ins += ["v_fma_f32 %s, v%d, v%d, %s" % (AX, px, T2[1], AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, T2[1], AY),
@@ -258,8 +354,8 @@ def build_f64(pad):
     return ins
 
 
-def check(ins):
-    """the hardware rules the loop is built on"""
+def check(ins, strict=True):
+    """the hardware rules the loop is built on (strict: every 8-byte instruction of the loop starts at 4 mod 8 bytes)"""
     # position of the loop head relative to the 64-byte line set by .p2align 6
     pre = ins[ins.index(".p2align 6") + 1:ins.index("1:")]
     head = sum(0 if i.endswith(":") else 4 for i in pre)      # only 4-byte scalar instructions there
@@ -272,23 +368,25 @@ def check(ins):
         if i.endswith(":"):
             continue
         op = i.split()[0]
-        size = 4 if op.startswith("s_") and not op.startswith("s_load") else 8
+        size = 4 if (op.startswith("s_") and not op.startswith("s_load")) or op.endswith("_e32") else 8
         if op.startswith("v_"):
-            assert op.endswith("_e64") or op == "v_fma_f32", i                       # every VALU encoding is 64-bit
-            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", i)][1:]
+            assert op.endswith("_e64") or op.endswith("_e32") or op == "v_fma_f32", i
+            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", i)]
+            regs = regs if op.startswith("v_fmac") else regs[1:]                     # fmac reads its destination
             if len(regs) == 3:
                 assert len({r & 1 for r in regs}) == 2, i                            # never three same-parity VGPR reads
         if size == 8:
-            assert nbytes % 8 == 0, i                                                # 4-byte instructions only in pairs
+            if strict:
+                assert nbytes % 8 == 0, i                                            # 4-byte instructions only in pairs
             if op.startswith("v_") and first_valu is None:
                 first_valu = (head + nbytes) % 8
         nbytes += size
-    assert nbytes % 8 == 0
+    assert not strict or nbytes % 8 == 0
     return head % 64, first_valu
 
 
 def main():
-    regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ, BX, BY, BZ)]))
+    regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ, BX, BY, BZ, EPSV)] + [40, 41, 42, 43, 44]))
     clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(PTR, FULL + 1)] + ["scc", "memory"]
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_force_loop.py — do not edit.  See that file for the why.\n")
@@ -302,6 +400,17 @@ def main():
         ins = build(15 - HEAD_BYTES // 4, SHORT, stagger=True)
         assert check(ins) == (60, 4)
         f.write("#define NB_FORCE_LOOP_V2 \"%s\"\n" % "\\n\\t".join(ins))
+        for v, (nr, nl) in ((3, (True, False)), (4, (False, True)), (5, (True, True))):
+            ins = diagnostic(build(15 - HEAD_BYTES // 4), nr, nl)
+            assert check(ins) == (60, 4)
+            f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
+        for v, style, strict in ((9, "e32sub", True), (10, "e32sub_nofill", False), (11, "e32all", False), (12, "e64", True), (13, "e32sub_seps", True)):
+            ins = build(15 - HEAD_BYTES // 4, style=style)
+            assert check(ins, strict)[0] == 60 and (not strict or check(ins, strict)[1] == 4), (style, check(ins, strict))
+            f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
+        for v, kind in ((6, "indep"), (7, "e32"), (8, "vgprsrc"), (14, "vgprsrc_rsq"), (15, "vgprsrc_rsq_lds")):
+            ins = build(15 - HEAD_BYTES // 4, diag=kind)
+            f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         ins = build(15 - HEAD_BYTES // 4, LONG)
         assert check(ins) == (60, 4)
         f.write("#define NB_FORCE_LOOP_LONG \"%s\"\n" % "\\n\\t".join(ins))

@@ -38,7 +38,10 @@ def main():
     eng = nb.NBody(n, fp64=args.fp64, tile=args.tile)
     eng.set_option(nb.OPT_TIMING, 0 if args.wall else 1)
     import time
-    vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, "isa0": nb.VARIANT_ISA, "isa1": nb.VARIANT_ISA, "isa2": nb.VARIANT_ISA}
+    vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, "isa0": nb.VARIANT_ISA, "isa1": nb.VARIANT_ISA, "isa2": nb.VARIANT_ISA,
+            "isa3": nb.VARIANT_ISA, "isa4": nb.VARIANT_ISA, "isa5": nb.VARIANT_ISA,   # isa3..8: timing-only diagnostics
+            "isa6": nb.VARIANT_ISA, "isa7": nb.VARIANT_ISA, "isa8": nb.VARIANT_ISA, "isa9": nb.VARIANT_ISA, "isa10": nb.VARIANT_ISA,
+            "isa11": nb.VARIANT_ISA, "isa12": nb.VARIANT_ISA, "isa13": nb.VARIANT_ISA, "isa14": nb.VARIANT_ISA, "isa15": nb.VARIANT_ISA}
     res = {c: [] for c in cfgs}
     for rnd in range(args.rounds):
         for c in cfgs:
