@@ -66,10 +66,14 @@ enum {
                               >= 4 workgroups per CU, where the hand-off hides behind other workgroups, else two.  Same bits. */
   NBODY_OPT_GRAPH = 12,    /* 1 (default): nbody_step on one GPU replays a HIP graph of two steps; 0: launch every kernel */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
-  NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: 1 = the product loop (default); 0 = the same instructions placed one 4-byte
-                              phase off — 27 % slower, kept so that the code-placement effect can be re-measured; 2 = staggered
-                              s_load_dwordx8 delivery (-3 %); 3, 4, 5 = TIMING-ONLY diagnostic loops WITH WRONG RESULTS (no
-                              transcendental / no scalar loads / neither) that price those parts inside the real kernel */
+  NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: which generated form of the hand-scheduled loop runs (tools/gen_force_loop.py).
+                              1 = the product loop (default).  Kept so that the measurements in profiles/r02_loop_diagnostics.md
+                              can be repeated: 0 = the same instructions placed one 4-byte phase off (-27 %); 2 = staggered
+                              s_load_dwordx8 delivery (-3 %); 9, 10, 11, 13 = 32-bit encodings of the subtractions / of
+                              everything (-4 .. -31 %); 12 = round 1's loop (eps in an SGPR, -0.4 .. -1 %) — all of these
+                              bit-identical to the product loop.  3..8, 14, 15 = TIMING-ONLY diagnostic loops WITH WRONG
+                              RESULTS (no transcendental, no scalar loads, VGPR-sourced operands, an LDS read per source, ...)
+                              that price one part of the loop inside the real kernel; never use them for results. */
 };
 enum { NBODY_VARIANT_AUTO = 0,     /* ISA for the timed arithmetic (fp32, FMA3, blocked or sequential sum), else SMEM */
        NBODY_VARIANT_SMEM = 1,     /* wave-uniform scalar loads (s_load_dwordx16) into SGPRs: no LDS, no VALU cost */
