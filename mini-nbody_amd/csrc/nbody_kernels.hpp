@@ -800,13 +800,24 @@ __global__ void __launch_bounds__(kBlock) combine_kernel(ForceArgs a) {
   const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.row0 + a.row_count) return;
   const V4* part = (const V4*)a.partial;
-  V4 f = part[i];
-  for (int sg = 1; sg < a.nseg; ++sg) {
-    V4 p = part[(size_t)sg * a.n_rows + i];
-    f.x = f.x + p.x; f.y = f.y + p.y; f.z = f.z + p.z;
-  }
   const V4 me = ((const V4*)a.rows)[i];
-  apply_force<T, V4>(a, i, me, f.x, f.y, f.z);
+  // 16 partials in flight (this kernel is latency: at small N it is a handful of workgroups), added in ascending order
+  constexpr int C = 16;
+  T fx = (T)0, fy = (T)0, fz = (T)0;
+  for (int sg0 = 0; sg0 < a.nseg; sg0 += C) {
+    V4 p[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+      if (sg0 + k < a.nseg) p[k] = part[(size_t)(sg0 + k) * a.n_rows + i];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      if (sg0 + k < a.nseg) {
+        if (sg0 + k == 0) { fx = p[k].x; fy = p[k].y; fz = p[k].z; }
+        else { fx = fx + p[k].x; fy = fy + p[k].y; fz = fz + p[k].z; }
+      }
+    }
+  }
+  apply_force<T, V4>(a, i, me, fx, fy, fz);
 }
 
 // integrate(): r += v * dt for the rank's bodies, in place.

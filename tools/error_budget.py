@@ -84,7 +84,7 @@ def main():
 
             for name, opts in (
                 ("GPU timed mode (v_rsq_f32), DEFAULT configuration", {}),
-                ("GPU v_rsq_f32, blocked, 8 slices x auto (the 8-GPU order)", {nb.OPT_JSLICES: 8}),
+                ("GPU v_rsq_f32, blocked, 8 slices x 8 pieces (the 8-GPU order at N = 1M)", {nb.OPT_JSLICES: 8, nb.OPT_JSUB: 8}),
                 ("GPU v_rsq_f32, ONE sequential sum", {nb.OPT_JSUB: 1, nb.OPT_SUM_ORDER: nb.SUM_SEQ}),
                 ("GPU v_rsq_f32, sequential, default segmentation (round 1's timed path)", {nb.OPT_SUM_ORDER: nb.SUM_SEQ}),
                 ("GPU v_rsq_f32, FPGA order, 1 segment", {nb.OPT_JSUB: 1, nb.OPT_SUM_ORDER: nb.SUM_FPGA16}),
