@@ -75,9 +75,11 @@ def body(k, sbase, b, style="vgpreps"):
     px, py, pz = DSETS[(k - 1) & 1]
     s0 = sbase + 4 * b
     if style != "e64":
-        sub = "v_sub_f32_e64" if style == "vgpreps" else "v_sub_f32_e32"
+        sub = "v_sub_f32_e64" if style in ("vgpreps", "subrev") else "v_sub_f32_e32"
         eps = EPS if style == "e32sub_seps" else EPSV
         out = ["%s v%d, s%d, %s" % (sub, dx, s0, XI), "%s v%d, s%d, %s" % (sub, dy, s0 + 1, YI), "%s v%d, s%d, %s" % (sub, dz, s0 + 2, ZI)]
+        if style == "subrev":   # the SGPR in src1 instead of src0: D = S1 - S0 = target - this, the same value
+            out = ["v_subrev_f32_e64 v%d, %s, s%d" % (dx, XI, s0), "v_subrev_f32_e64 v%d, %s, s%d" % (dy, YI, s0 + 1), "v_subrev_f32_e64 v%d, %s, s%d" % (dz, ZI, s0 + 2)]
         if style in ("e32sub", "e32sub_seps"):
             out.append("s_nop 0")
         out.append("v_fma_f32 v%d, v%d, v%d, %s" % (t, dz, dz, eps))
@@ -404,7 +406,7 @@ def main():
             ins = diagnostic(build(15 - HEAD_BYTES // 4), nr, nl)
             assert check(ins) == (60, 4)
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
-        for v, style, strict in ((9, "e32sub", True), (10, "e32sub_nofill", False), (11, "e32all", False), (12, "e64", True), (13, "e32sub_seps", True)):
+        for v, style, strict in ((9, "e32sub", True), (10, "e32sub_nofill", False), (11, "e32all", False), (12, "e64", True), (13, "e32sub_seps", True), (16, "subrev", True)):
             ins = build(15 - HEAD_BYTES // 4, style=style)
             assert check(ins, strict)[0] == 60 and (not strict or check(ins, strict)[1] == 4), (style, check(ins, strict))
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
