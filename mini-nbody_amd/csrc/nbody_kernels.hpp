@@ -11,13 +11,15 @@
 //     inv3 = inv * (inv * inv)           2 v_mul_f32            S/cube.vhd:66-70
 //     F += d * inv3                      3 v_fma_f32            S/fxyz.vhd:120-127
 // = 11 full-rate VALU (2 cycles per wave64 on a SIMD) + 1 quarter-rate
-// transcendental (8 cycles): 30 cycles per 64 pairs per SIMD, measured
-// (profiles/r01_microbench_valu_issue.txt).  That issue count, not HBM and not
-// MFMA, bounds the kernel.  v_pk_*_f32 cost 4 cycles on gfx950 (same file), so
-// packed math buys nothing and is kept out (-fno-slp-vectorize).
+// transcendental (8 cycles): 30 cycles per 64 pairs per SIMD by the instruction
+// costs of profiles/r01_microbench_valu_issue.txt; inside the real kernel 33.0-33.4
+// (the full-rate instructions that read an SGPR cost 2.27, the transcendental 8.4:
+// profiles/r02_loop_diagnostics.md).  That issue count, not HBM and not MFMA, bounds
+// the kernel.  v_pk_*_f32 cost 4 cycles on gfx950, so packed math buys nothing and is
+// kept out (-fno-slp-vectorize).
 //
 // The three variants differ only in how r_j reaches the lanes:
-//   SMEM      wave-uniform scalar loads into SGPRs; VALU reads them as scalar operands (free)
+//   SMEM      wave-uniform scalar loads into SGPRs; VALU reads them as scalar operands (no instruction spent)
 //   LDS       TILE bodies staged in LDS, every lane reads the same address (broadcast ds_read_b128)
 //   READLANE  each lane holds one body of a 64-body wave tile; v_readlane_b32 x3 per source (4 cycles each)
 // All of them add the sources of a segment in the same order, so they return
@@ -30,9 +32,9 @@
 // sequential sum (study mode; what a CPU nbody.c does).
 //
 // How a row's force is finished (ForceArgs::finish): with one segment the kernel applies kick and drift itself;
-// with several, every workgroup stores its partial sum and the LAST workgroup to arrive for a block of rows (an
-// agent-scope ticket per row block) adds the partials in ascending segment order and applies kick and drift — one
-// launch per step, and the result does not depend on which workgroup came last.
+// with several, every wave stores its partial sums and the LAST wave to arrive for its rows (an agent-scope ticket
+// per wave of a row block) adds the partials in ascending segment order and applies kick and drift — one launch per
+// step, and the result does not depend on which wave came last; or (small launches) a combine kernel does, same bits.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

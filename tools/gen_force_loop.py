@@ -15,7 +15,7 @@ profiles/r01_sweep_isa.txt):
         sub sub sub | fma fma fma | rsq | 3 accumulating fma of the PREVIOUS body | mul mul
     — the previous body's accumulates are the wait state, and this was the fastest legal single-chain order in the
     stream harness (ord_defA, 2.63 cycles/instruction).
-  * live-in / live-out values are copied into fixed registers (v8-v17, s33) so that the loop's bytes, banks and
+  * live-in / live-out values are copied into fixed registers (v8-v18, s33) so that the loop's bytes, banks and
     placement do not depend on hipcc's register allocation around the asm statement; the loop head sits 60 bytes
     past a 64-byte line.
   * a single fp32 accumulator per axis is off by 1e-4 of the force after 2^20 terms; the reference keeps 16 partial
@@ -24,10 +24,10 @@ profiles/r01_sweep_isa.txt):
     restart from zero — 3 v_add + 7 v_mov + 4 scalar instructions per 12288 VALU instructions.
 
 Loop shape (one wave, one body i per lane, sources delivered as wave-uniform scalar loads):
-    A = s[36:51], B = s[52:67]: two buffers of 4 bodies {x,y,z,w}; pointer s[68:69], group counter s70, stride s71,
-    groups left s72, groups per block s73
+    A = s[36:51], B = s[52:67]: two buffers of 4 bodies {x,y,z,w}; pointer s[34:35], group counter s68, stride s69,
+    groups left s70, groups per block s71, full-block flag s72 (79 SGPRs with VCC etc.: 8 waves per SIMD fit)
     prologue: load A
-    block: s70 = min(s72, s73) groups
+    block: s68 = min(s70, s71) groups
       loop:  wait A | load B | 4 bodies from A (48 VALU) | advance pointer | wait B | load A (next group) | 4 bodies from B
       accumulate the block's last body; a full block is folded into level 2, a short one (the segment's last) is left
       in level 1 for the caller
@@ -35,8 +35,11 @@ Loop shape (one wave, one body i per lane, sources delivered as wave-uniform sca
 The arithmetic and its order per body are exactly pair_f32<0> of nbody_kernels.hpp (sources ascending), so the result
 is bit-identical to the C++ kernels (tests/test_gpu_parity.py).
 
-Variants emitted: NB_FORCE_LOOP_V1 = the product loop (head 60 bytes past a 64-byte line); NB_FORCE_LOOP_V0 = the same
-instructions one 4-byte phase off (head at 56), kept only so that the placement effect can be re-measured (NBODY_OPT_ISA_PHASE = 0: 3.4k vs 4.6k G/s).
+Forms emitted (NBODY_OPT_ISA_PHASE selects one; include/nbody.h lists them): NB_FORCE_LOOP_V1 = the product loop (head 60
+bytes past a 64-byte line, eps from a VGPR); V0 = the same instructions one 4-byte phase off (3.4k vs 4.6k G/s); V2 staggered
+s_load_dwordx8; V9-V13, V16 other encodings of the SGPR-reading instructions (all bit-identical, all slower); V3-V8, V14, V15
+TIMING-ONLY diagnostic forms with wrong results that price one part of the loop inside the real kernel
+(profiles/r02_loop_diagnostics.md); NB_FORCE_LOOP_LONG = 8-body buffers for launches with few waves per SIMD.
 Bring-up experiments that did not help (16-source groups, base+offset addressing, fused count-down, loads issued
 mid-buffer, other in-body orders) are recorded in DESIGN.md §3.1 and in the git history of this file.
 """
