@@ -16,7 +16,7 @@ Rank 0 prints ONE JSON line, always with:
   roofline      the force kernel priced at 20 flop per pair against the fp32 (157.3 TFLOP/s) or
                 fp64 (78.6) VECTOR peak — the path has no contraction for the matrix cores — with the kernel's
                 duration measured live by HIP events on the library's compute stream; beside it the instruction-issue
-                bound (30 cycles per wave-pair in fp32, 88 in fp64) and cycles per wave-pair.  `traffic` and the
+                bound (30 cycles per wave-pair in fp32, 80 in fp64) and cycles per wave-pair.  `traffic` and the
                 other *_pmc fields come from the committed rocprofv3 passes of THIS configuration
                 (profiles/pmc_*.json, tools/profile.sh) and are attached only when that profile's recorded
                 configuration equals the run's; otherwise `traffic` is null.
@@ -40,9 +40,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FLOP_PER_PAIR = 20                # SURVEY.md §8(d) convention (literal count: 18)
 PEAK_VECTOR_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 (32) flop/clk x 2.4 GHz
-# cycles of VALU issue per wave64 pair: fp32 11 x 2 + 8 (v_rsq_f32); fp64 18 x 4 + 16 (v_rsq_f64)
+# cycles of VALU issue per wave64 pair: fp32 11 x 2 + 8 (v_rsq_f32); fp64 16 x 4 + 16 (v_rsq_f64)
 # measured: profiles/r01_microbench_valu_issue.txt, DESIGN.md §3
-ISSUE_CYCLES_PER_WAVE_PAIR = {"f32": 30, "f64": 88}
+ISSUE_CYCLES_PER_WAVE_PAIR = {"f32": 30, "f64": 80}
 METRIC = "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofline"
 
 
@@ -236,7 +236,7 @@ def main():
                 "frac_of_issue_bound": round(kernel_rate / issue_bound, 4) if issue_bound else None,
                 "cycles_per_wave_pair_at_nominal_clock": round(avg_launch_s * clk * simds / wave_pairs_per_launch, 2) if wave_pairs_per_launch else None,
                 "note": "VALU-issue-bound: per pair 11 full-rate + 1 quarter-rate instruction in fp32 (30 cycles per wave64), "
-                        "18 + 1 in fp64 (88); neither HBM nor MFMA bounds it (no contraction; HBM traffic is 64 B per body per step)"}
+                        "16 + 1 in fp64 (80); neither HBM nor MFMA bounds it (no contraction; HBM traffic is 64 B per body per step)"}
         pj = matching_pmc(run_cfg)
         if pj:
             roof["traffic"] = pj.get("hbm_bytes_per_launch")

@@ -133,18 +133,18 @@ __device__ __forceinline__ void pair_f32(float xj, float yj, float zj, float xi,
   az = __builtin_fmaf(dz, inv3, az);
 }
 
-// fp64: v_rsq_f64 seed (about 2^-27 relative) + two Newton steps y <- y + y*(1/2 - (x/2)*y*y), 7 operations;
-// same expression tree as oracle/nbody_ref.c ref_forces_f64 apart from how 1/sqrt is obtained, and the same
-// operations in the same order as the hand-scheduled fp64 loop (tools/gen_force_loop.py body_f64).
+// fp64: v_rsq_f64 seed (about 2^-24 relative) + ONE third-order step: with e = 1 - x*y*y,
+//   x^(-1/2) = y (1 - e)^(-1/2) = y (1 + e/2 + 3/8 e^2 + 5/16 e^3 + ...),   y <- y + y*e*(1/2 + 3/8 e)
+// leaves (5/16) e^3 < 2^-70: full binary64 in 5 operations (round 1: two Newton steps, 7 operations).  Same
+// expression tree as oracle/nbody_ref.c ref_forces_f64 apart from how 1/sqrt is obtained, and the same operations in
+// the same order as the hand-scheduled fp64 loop (tools/gen_force_loop.py body_f64).
 __device__ __forceinline__ double rsqrt_f64(double x) {
   double y = __builtin_amdgcn_rsq(x);
-  double hx = x * 0.5;
-  double r = hx * y;
-  double e = __builtin_fma(-r, y, 0.5);
-  y = __builtin_fma(y, e, y);
-  r = hx * y;
-  e = __builtin_fma(-r, y, 0.5);
-  y = __builtin_fma(y, e, y);
+  double r = x * y;
+  double e = __builtin_fma(-r, y, 1.0);
+  double p = __builtin_fma(e, 0.375, 0.5);
+  double q = e * p;
+  y = __builtin_fma(y, q, y);
   return y;
 }
 __device__ __forceinline__ void pair_f64(double xj, double yj, double zj, double xi, double yi, double zi, double eps,

@@ -314,17 +314,20 @@ def body_f64(k, sbase, b):
         "v_fma_f64 %s, %s, %s, %s" % (vp(D_AX), vp(px), vp(yp), vp(D_AX)),
         "v_fma_f64 %s, %s, %s, %s" % (vp(D_AY), vp(py), vp(yp), vp(D_AY)),
         "v_fma_f64 %s, %s, %s, %s" % (vp(D_AZ), vp(pz), vp(yp), vp(D_AZ)),
-        "v_mul_f64 %s, %s, 0.5" % (vp(D_HX), vp(D_T)),
     ]
-    for _ in range(2):
-        out += ["v_mul_f64 %s, %s, %s" % (vp(D_R), vp(D_HX), vp(y)),
-                "v_fma_f64 %s, -%s, %s, 0.5" % (vp(D_E), vp(D_R), vp(y)),
-                "v_fma_f64 %s, %s, %s, %s" % (vp(y), vp(y), vp(D_E), vp(y))]
+    # one third-order step from the v_rsq_f64 seed (rsqrt_f64 in nbody_kernels.hpp): e = 1 - x*y*y,
+    # y <- y + y*e*(1/2 + 3/8 e): the error goes from e0 to (5/16) e0^3, full binary64 from a 2^-24 seed in 5 operations
+    out += ["v_mul_f64 %s, %s, %s" % (vp(D_R), vp(D_T), vp(y)),
+            "v_fma_f64 %s, -%s, %s, 1.0" % (vp(D_E), vp(D_R), vp(y)),
+            "v_fma_f64 %s, %s, %s, 0.5" % (vp(D_HX), vp(D_E), sp(D_K375)),
+            "v_mul_f64 %s, %s, %s" % (vp(D_E), vp(D_E), vp(D_HX)),
+            "v_fma_f64 %s, %s, %s, %s" % (vp(y), vp(y), vp(D_E), vp(y))]
     out += ["v_mul_f64 %s, %s, %s" % (vp(D_U), vp(y), vp(y)), "v_mul_f64 %s, %s, %s" % (vp(y), vp(y), vp(D_U))]
     return out
 
 
 F64_PTR, F64_CNT, F64_STRIDE = 68, 70, 71    # the fp64 loop keeps its own scalars (it is VGPR-limited to 5 waves anyway)
+D_K375 = 72                                  # s[72:73] = 0.375 (VOP3 takes no literal on gfx9: the constant lives in an SGPR pair)
 
 
 def build_f64(pad):
@@ -336,6 +339,7 @@ def build_f64(pad):
         "s_mov_b64 s[%d:%d], %%[p]" % (F64_PTR, F64_PTR + 1),
         "s_mov_b32 s%d, %%[groups]" % F64_CNT,
         "s_movk_i32 s%d, 0x80" % F64_STRIDE,
+        "s_mov_b32 s%d, 0" % D_K375, "s_mov_b32 s%d, 0x3fd80000" % (D_K375 + 1),
         "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, F64_PTR, F64_PTR + 1),
     ]
     ins += ["v_mov_b64 %s, 0" % vp(r) for r in (px, py, pz, D_Y[1])]
@@ -425,7 +429,7 @@ def main():
         f.write("#define NB_FORCE_LOOP_LONG_GROUP %d\n" % GROUP_LONG)
         for v, pad in ((0, 14), (1, 15)):
             f.write("#define NB_FORCE_LOOP_F64_V%d \"%s\"\n" % (v, "\\n\\t".join(build_f64(pad))))
-        clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, F64_STRIDE + 1)] + ["scc", "memory"]
+        clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, D_K375 + 2)] + ["scc", "memory"]
         f.write("#define NB_FORCE_LOOP_F64_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob64))
         f.write("#define NB_FORCE_LOOP_F64_GROUP %d\n" % GROUP_F64)
     n_valu = len([i for i in build(11) if i.startswith("v_")])
