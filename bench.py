@@ -98,6 +98,15 @@ def cpu_baseline(n, seed, fp64):
                       % (what, rows, n, n, t, "-march=native" if path else "-march=x86-64-v3")}
 
 
+def kernel_source_sha():
+    """identifies the kernel code a profile was taken on (a profile of an older loop must not be attached to a new one)"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("nbody_kernels.hpp", "force_loop_gfx950.inc", "nbody_hip.hip"):
+        h.update(open(os.path.join(ROOT, "mini-nbody_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def matching_pmc(run_cfg):
     """profiles/pmc_*.json written by tools/parse_prof.py for the SAME configuration (bodies, precision, ranks, variant,
     segments, block length, launches per step), or None: counters cannot be read from inside the timed process."""
@@ -224,7 +233,8 @@ def main():
         issue_bound = simds * 64.0 / ISSUE_CYCLES_PER_WAVE_PAIR[dtype] * clk   # pairs/s at the nominal clock
         wave_pairs_per_launch = pairs_per_launch / 64.0
         run_cfg = {"n": n, "dtype": dtype, "n_gpus": world, "variant": cfg["variant"], "iblock": cfg["iblock"], "nseg": cfg["nseg"],
-                   "sum_order": cfg["sum_order"], "sum_block": cfg["sum_block"], "launches_per_step": cfg["launches_per_step"]}
+                   "sum_order": cfg["sum_order"], "sum_block": cfg["sum_block"], "launches_per_step": cfg["launches_per_step"],
+                   "kernel_source_sha": kernel_source_sha()}
         roof = {"bound": "valu", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / peak, 4), "traffic": None, "flop_per_pair": FLOP_PER_PAIR,
                 "kernel_ms_avg": round(avg_launch_s * 1e3, 4), "kernel_launches": launches,
@@ -254,7 +264,7 @@ def main():
             "config": {"workload": "N=%d %s all-pairs softened gravity, leapfrog kick-drift, dt=0.01, seed %d"
                                    % (n, "fp64" if args.fp64 else "fp32", args.seed),
                        "n_bodies": n, "pairs_per_step": pairs_per_step, "parallelism": "bodies sharded over %d GPU(s)" % world,
-                       "kernel": cfg, "comm": (args.comm + " / " + getattr(eng, "transport", "rccl") + " / overlap %d" % args.overlap) if world > 1 else None,
+                       "kernel": cfg, "kernel_source_sha": kernel_source_sha(), "comm": (args.comm + " / " + getattr(eng, "transport", "rccl") + " / overlap %d" % args.overlap) if world > 1 else None,
                        "finite": finite},
             "roofline": roof,
         }

@@ -57,7 +57,8 @@ def main():
     if bench:
         k = bench["config"]["kernel"]
         cfg = {"n": bench["config"]["n_bodies"], "dtype": bench["dtype"], "n_gpus": bench["n_gpus"], "variant": k["variant"], "iblock": k["iblock"],
-               "nseg": k["nseg"], "sum_order": k["sum_order"], "sum_block": k["sum_block"], "launches_per_step": k["launches_per_step"]}
+               "nseg": k["nseg"], "sum_order": k["sum_order"], "sum_block": k["sum_block"], "launches_per_step": k["launches_per_step"],
+               "kernel_source_sha": bench["config"].get("kernel_source_sha")}
         wave_pairs = float(k["n_local"]) * bench["config"]["n_bodies"] / 64.0
     if durs and "GRBM_GUI_ACTIVE" in avg:
         t = sum(durs) / len(durs) * 1e-9
