@@ -177,6 +177,11 @@ void resolve_config() {
     int slice_len = g.n / g.nslices;
     int max_sub = std::max(1, slice_len / 128);    // keep >= 128 sources per segment (a wave walks its segment serially)
     sub = std::max(sub, (slice_len + 131071) / 131072);   // and <= 131072 sources (a workgroup's lifetime: the launch's tail)
+    // ... unless the partial sums (nseg words per body) would then exceed 1 GiB per rank: at that size (N >= 8M fp32,
+    // 4M fp64) a workgroup's lifetime is a negligible part of a step of many seconds anyway; never below 8 segments a step
+    const long long words_cap = (1LL << 30) / (long long)word_bytes() / n_local;
+    const int mem_sub = (int)std::max(1LL, std::max(8LL, words_cap) / g.nslices);
+    sub = std::min(sub, std::max(mem_sub, (target_blocks + blocks - 1) / blocks));
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
   }
   g.sub = sub;

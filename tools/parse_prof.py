@@ -22,7 +22,8 @@ def main():
         bench = json.loads(txt[-1])
     except Exception:
         pass
-    stats = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
+    # gpurun merges a call's files into what an earlier call left in the same directory: keep the newest file per pass
+    stats = sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
     force_avg_ns = None
     force_name = None
     if stats:
@@ -37,7 +38,12 @@ def main():
     counters = defaultdict(list)
     durs = []
     meta = {}
+    newest = {}
     for f in glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv")):
+        key = f.split(os.sep)[-3]
+        if key not in newest or os.path.getmtime(f) > os.path.getmtime(newest[key]):
+            newest[key] = f
+    for f in newest.values():
         for r in csv.DictReader(open(f)):
             if "force_" not in r["Kernel_Name"]:
                 continue
