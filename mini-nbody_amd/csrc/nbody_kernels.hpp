@@ -498,6 +498,8 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
       NB_DIAG_LOOP(NB_FORCE_LOOP_V13);
     } else if constexpr (PLACEMENT == 16) {   // correct: SGPR operand in src1 (v_subrev)
       NB_DIAG_LOOP(NB_FORCE_LOOP_V16);
+    } else if constexpr (PLACEMENT == 17) {   // correct: dx, dy in one packed subtraction (11 instructions per pair)
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V17);
     } else if constexpr (PLACEMENT == 14) {   // 14, 15: TIMING-ONLY (wrong results): VGPR-sourced coordinates with the transcendental, + an LDS read per source
       NB_DIAG_LOOP(NB_FORCE_LOOP_V14);
     } else if constexpr (PLACEMENT == 15) {

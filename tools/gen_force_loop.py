@@ -37,7 +37,7 @@ is bit-identical to the C++ kernels (tests/test_gpu_parity.py).
 
 Forms emitted (NBODY_OPT_ISA_PHASE selects one; include/nbody.h lists them): NB_FORCE_LOOP_V1 = the product loop (head 60
 bytes past a 64-byte line, eps from a VGPR); V0 = the same instructions one 4-byte phase off (3.4k vs 4.6k G/s); V2 staggered
-s_load_dwordx8; V9-V13, V16 other encodings of the SGPR-reading instructions (all bit-identical, all slower); V3-V8, V14, V15
+s_load_dwordx8; V9-V13, V16, V17 other encodings of the SGPR-reading instructions (all bit-identical, all slower); V3-V8, V14, V15
 TIMING-ONLY diagnostic forms with wrong results that price one part of the loop inside the real kernel
 (profiles/r02_loop_diagnostics.md); NB_FORCE_LOOP_LONG = 8-body buffers for launches with few waves per SIMD.
 Bring-up experiments that did not help (16-source groups, base+offset addressing, fused count-down, loads issued
@@ -77,6 +77,20 @@ def body(k, sbase, b, style="vgpreps"):
     dx, dy, dz = DSETS[k & 1]
     px, py, pz = DSETS[(k - 1) & 1]
     s0 = sbase + 4 * b
+    if style == "pksub":
+        # experiment: dx and dy in ONE packed subtraction (v_pk_add_f32 with src1 negated: the same IEEE result), so the
+        # SGPR-operand surcharge is paid twice per pair instead of three times; 11 instructions per pair instead of 12.
+        # Needs (dx, dy) in an aligned register pair, so the parities differ from the product loop's: see build_pk()
+        assert dy == dx + 1 and dx % 2 == 0
+        return ["v_pk_add_f32 v[%d:%d], s[%d:%d], v[8:9] neg_lo:[0,1] neg_hi:[0,1]" % (dx, dy, s0, s0 + 1),
+                "v_sub_f32_e64 v%d, s%d, %s" % (dz, s0 + 2, ZI),
+                "v_fma_f32 v%d, v%d, v%d, %s" % (t, dz, dz, EPSV),
+                "v_fma_f32 v%d, v%d, v%d, v%d" % (PK_T, dy, dy, t),
+                "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dx, dx, PK_T),
+                "v_rsq_f32_e64 v%d, v%d" % (t, t),
+                "v_fma_f32 %s, v%d, v%d, %s" % (AX, px, tp, AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, tp, AY),
+                "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, tp, AZ),
+                "v_mul_f32_e64 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e64 v%d, v%d, v%d" % (t, t, U)]
     if style != "e64":
         sub = "v_sub_f32_e64" if style in ("vgpreps", "subrev") else "v_sub_f32_e32"
         eps = EPS if style == "e32sub_seps" else EPSV
@@ -279,6 +293,22 @@ def build(pad, m=SHORT, stagger=False, diag=None, style="vgpreps"):
     return ins
 
 
+PK_T = 25                                     # odd: d2 after the dy term
+PK_DSETS = [(26, 27, 21), (28, 29, 23)]       # (dx, dy) an aligned pair, dz odd
+PK_AX = "v11"                                 # odd: fma(AX, dx (even), inv3 (even), AX) must not read three even registers
+
+
+def build_pk(pad):
+    """the product loop with style "pksub" and the register parities that form needs"""
+    global DSETS, AX
+    keep = DSETS, AX
+    DSETS, AX = PK_DSETS, PK_AX
+    try:
+        return build(pad, style="pksub")
+    finally:
+        DSETS, AX = keep
+
+
 # ---- fp64 (BASELINE config 5's arithmetic): same structure, 19 instructions per pair, all VOP3 (8 bytes) once
 # v_rsq_f64 is written in its 64-bit encoding; 4 sources per iteration (two buffers of 2 bodies x 32 bytes).
 # 1/sqrt = v_rsq_f64 seed + two Newton steps in the 7-operation form of rsqrt_f64() in nbody_kernels.hpp
@@ -379,7 +409,7 @@ def check(ins, strict=True):
         op = i.split()[0]
         size = 4 if (op.startswith("s_") and not op.startswith("s_load")) or op.endswith("_e32") else 8
         if op.startswith("v_"):
-            assert op.endswith("_e64") or op.endswith("_e32") or op == "v_fma_f32", i
+            assert op.endswith("_e64") or op.endswith("_e32") or op in ("v_fma_f32", "v_pk_add_f32"), i
             regs = [int(x) for x in re.findall(r"\bv(\d+)\b", i)]
             regs = regs if op.startswith("v_fmac") else regs[1:]                     # fmac reads its destination
             if len(regs) == 3:
@@ -395,7 +425,7 @@ def check(ins, strict=True):
 
 
 def main():
-    regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ, BX, BY, BZ, EPSV)] + [40, 41, 42, 43, 44]))
+    regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ, BX, BY, BZ, EPSV)] + [40, 41, 42, 43, 44] + [PK_T, int(PK_AX[1:])] + [x for d in PK_DSETS for x in d]))
     clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(PTR, FULL + 1)] + ["scc", "memory"]
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_force_loop.py — do not edit.  See that file for the why.\n")
@@ -417,6 +447,9 @@ def main():
             ins = build(15 - HEAD_BYTES // 4, style=style)
             assert check(ins, strict)[0] == 60 and (not strict or check(ins, strict)[1] == 4), (style, check(ins, strict))
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
+        ins = build_pk(15 - HEAD_BYTES // 4)
+        assert check(ins) == (60, 4)
+        f.write("#define NB_FORCE_LOOP_V17 \"%s\"\n" % "\\n\\t".join(ins))
         for v, kind in ((6, "indep"), (7, "e32"), (8, "vgprsrc"), (14, "vgprsrc_rsq"), (15, "vgprsrc_rsq_lds")):
             ins = build(15 - HEAD_BYTES // 4, diag=kind)
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
