@@ -71,7 +71,8 @@ enum {
                               can be repeated: 0 = the same instructions placed one 4-byte phase off (-27 %); 2 = staggered
                               s_load_dwordx8 delivery (-3 %); 9, 10, 11, 13 = 32-bit encodings of the subtractions / of
                               everything (-4 .. -31 %); 12 = round 1's loop (eps in an SGPR, -0.4 .. -1 %); 16 = v_subrev (-0.8 %);
-                              17 = dx, dy in one v_pk_add_f32 (-9.5 %) — all of these
+                              17 = dx, dy in one v_pk_add_f32 (-9.5 %); 18 = eps from a VGPR instead of the
+                              v_fmaak_f32 literal (-0.3 %) — all of these
                               bit-identical to the product loop.  3..8, 14, 15 = TIMING-ONLY diagnostic loops WITH WRONG
                               RESULTS (no transcendental, no scalar loads, VGPR-sourced operands, an LDS read per source, ...)
                               that price one part of the loop inside the real kernel; never use them for results. */

@@ -385,6 +385,7 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
       case 15: return launch_timed(L, force_isa_f32<15>, grid, a);
       case 16: return launch_timed(L, force_isa_f32<16>, grid, a);   // correct: SGPR operand in src1
       case 17: return launch_timed(L, force_isa_f32<17>, grid, a);   // correct: dx, dy in one packed subtraction
+      case 18: return launch_timed(L, force_isa_f32<18>, grid, a);   // correct: eps from a VGPR instead of the v_fmaak_f32 literal
       default: break;
     }
     return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0>, grid, a) : launch_timed(L, force_isa_f32<1>, grid, a);
@@ -1029,7 +1030,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;
     case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
-    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 17) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
+    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 18) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); drop_step_graph(); return reconfigure(); }

@@ -500,6 +500,8 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
       NB_DIAG_LOOP(NB_FORCE_LOOP_V16);
     } else if constexpr (PLACEMENT == 17) {   // correct: dx, dy in one packed subtraction (11 instructions per pair)
       NB_DIAG_LOOP(NB_FORCE_LOOP_V17);
+    } else if constexpr (PLACEMENT == 18) {   // correct: eps from a VGPR (the product loop takes it as the literal of v_fmaak_f32)
+      NB_DIAG_LOOP(NB_FORCE_LOOP_V18);
     } else if constexpr (PLACEMENT == 14) {   // 14, 15: TIMING-ONLY (wrong results): VGPR-sourced coordinates with the transcendental, + an LDS read per source
       NB_DIAG_LOOP(NB_FORCE_LOOP_V14);
     } else if constexpr (PLACEMENT == 15) {

@@ -154,7 +154,7 @@ def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engin
     set_variant(nb, eng, "smem", 8, jsub=1, arith=nb.ARITH_FMA3)
     assert np.array_equal(bits(eng.forces(pos)), bits(ref))
     # the hand-scheduled ISA loop (both code-placement phases): same operations, same order, same bits
-    for phase in (0, 1, 2, 9, 10, 11, 12, 13, 16, 17):      # 2 = staggered loads, 9..13 = other encodings of the same operations
+    for phase in (0, 1, 2, 9, 10, 11, 12, 13, 16, 17, 18):      # 2 = staggered loads, 9..13 = other encodings of the same operations
         set_variant(nb, eng, "isa", 0, jsub=1)
         eng.set_option(nb.OPT_ISA_PHASE, phase)
         assert eng.config["variant"] == "isa" and eng.config["iblock"] == 1

@@ -36,7 +36,7 @@ The arithmetic and its order per body are exactly pair_f32<0> of nbody_kernels.h
 is bit-identical to the C++ kernels (tests/test_gpu_parity.py).
 
 Forms emitted (NBODY_OPT_ISA_PHASE selects one; include/nbody.h lists them): NB_FORCE_LOOP_V1 = the product loop (head 60
-bytes past a 64-byte line, eps from a VGPR); V0 = the same instructions one 4-byte phase off (3.4k vs 4.6k G/s); V2 staggered
+bytes past a 64-byte line, eps as the literal of v_fmaak_f32); V0 = the same instructions one 4-byte phase off (3.4k vs 4.6k G/s); V2 staggered
 s_load_dwordx8; V9-V13, V16, V17 other encodings of the SGPR-reading instructions (all bit-identical, all slower); V3-V8, V14, V15
 TIMING-ONLY diagnostic forms with wrong results that price one part of the loop inside the real kernel
 (profiles/r02_loop_diagnostics.md); NB_FORCE_LOOP_LONG = 8-body buffers for launches with few waves per SIMD.
@@ -59,15 +59,18 @@ PTR, CNT, STRIDE = 34, 68, 69      # highest SGPR of the loop: s72 -> 79 SGPRs w
 GROUP = 8
 
 
+SOFT_BITS = 0x3089705F   # S/dzsoft.vhd:177 (the engine's only softening: nbody_kernels.hpp kSoftBits)
 EPSV = "v18"    # eps in a VGPR (even: dz, dz, eps are then not three same-parity reads)
 
 
-def body(k, sbase, b, style="vgpreps"):
+def body(k, sbase, b, style="fmaak"):
     """body k of the group reads source b of the SGPR buffer at sbase; accumulates body k-1.
     style: how the instructions that read an SGPR are encoded.  Measured inside the real kernel
     (profiles/r02_loop_diagnostics.md): a VOP3 (64-bit) instruction with an SGPR source costs ~0.9 cycles more than the
     same instruction reading VGPRs; the 32-bit VOP2 encoding of v_sub_f32 with the SGPR in src0 costs ~0.2 more.
-      vgpreps every instruction VOP3, source coordinates from SGPRs, eps from a VGPR: THE PRODUCT LOOP (+0.4..1.0 % over e64)
+      fmaak   source coordinates from SGPRs (VOP3), eps as the 32-bit literal of v_fmaak_f32 (VOP2 + literal = 8 bytes,
+              the placement holds): THE PRODUCT LOOP — no SGPR and no third VGPR read for eps (+0.3 % over vgpreps)
+      vgpreps every instruction VOP3, source coordinates from SGPRs, eps from a VGPR (+0.4..1.0 % over e64; NBODY_OPT_ISA_PHASE 18)
       e64     every instruction VOP3, source coordinates and eps from SGPRs (round 1's loop; NBODY_OPT_ISA_PHASE 12)
       e32sub  the three subtractions VOP2 + one s_nop (keeps every 8-byte instruction at 4 mod 8), eps from a VGPR
       e32sub_nofill  the same without the s_nop (the phase alternates from body to body)
@@ -92,14 +95,17 @@ def body(k, sbase, b, style="vgpreps"):
                 "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, tp, AZ),
                 "v_mul_f32_e64 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e64 v%d, v%d, v%d" % (t, t, U)]
     if style != "e64":
-        sub = "v_sub_f32_e64" if style in ("vgpreps", "subrev") else "v_sub_f32_e32"
+        sub = "v_sub_f32_e64" if style in ("vgpreps", "subrev", "fmaak") else "v_sub_f32_e32"
         eps = EPS if style == "e32sub_seps" else EPSV
         out = ["%s v%d, s%d, %s" % (sub, dx, s0, XI), "%s v%d, s%d, %s" % (sub, dy, s0 + 1, YI), "%s v%d, s%d, %s" % (sub, dz, s0 + 2, ZI)]
         if style == "subrev":   # the SGPR in src1 instead of src0: D = S1 - S0 = target - this, the same value
             out = ["v_subrev_f32_e64 v%d, %s, s%d" % (dx, XI, s0), "v_subrev_f32_e64 v%d, %s, s%d" % (dy, YI, s0 + 1), "v_subrev_f32_e64 v%d, %s, s%d" % (dz, ZI, s0 + 2)]
         if style in ("e32sub", "e32sub_seps"):
             out.append("s_nop 0")
-        out.append("v_fma_f32 v%d, v%d, v%d, %s" % (t, dz, dz, eps))
+        if style == "fmaak":    # eps as the 32-bit literal of a VOP2 v_fmaak_f32 (8 bytes too): one VGPR read fewer per pair (S/dzsoft.vhd:201-202)
+            out.append("v_fmaak_f32 v%d, v%d, v%d, 0x%08x" % (t, dz, dz, SOFT_BITS))
+        else:
+            out.append("v_fma_f32 v%d, v%d, v%d, %s" % (t, dz, dz, eps))
         if style == "e32all":
             out += ["v_fmac_f32_e32 v%d, v%d, v%d" % (t, dy, dy), "v_fmac_f32_e32 v%d, v%d, v%d" % (t, dx, dx),
                     "v_rsq_f32_e32 v%d, v%d" % (t, t),
@@ -204,7 +210,7 @@ def diag_body(kind, k, sbase, b):
     raise ValueError(kind)
 
 
-def build(pad, m=SHORT, stagger=False, diag=None, style="vgpreps"):
+def build(pad, m=SHORT, stagger=False, diag=None, style="fmaak"):
     """pad: s_nop count after .p2align 6, so that the inner loop's head `1:` sits 4*pad + HEAD_BYTES bytes past a
     64-byte line (60 for the product loop: every VALU instruction of the loop then starts at 4 mod 8 bytes).
     m: register map.  SHORT = the product loop: buffers of 4 bodies, a buffer's load is in flight for the 48 VALU
@@ -409,7 +415,7 @@ def check(ins, strict=True):
         op = i.split()[0]
         size = 4 if (op.startswith("s_") and not op.startswith("s_load")) or op.endswith("_e32") else 8
         if op.startswith("v_"):
-            assert op.endswith("_e64") or op.endswith("_e32") or op in ("v_fma_f32", "v_pk_add_f32"), i
+            assert op.endswith("_e64") or op.endswith("_e32") or op in ("v_fma_f32", "v_pk_add_f32", "v_fmaak_f32"), i
             regs = [int(x) for x in re.findall(r"\bv(\d+)\b", i)]
             regs = regs if op.startswith("v_fmac") else regs[1:]                     # fmac reads its destination
             if len(regs) == 3:
@@ -443,7 +449,7 @@ def main():
             ins = diagnostic(build(15 - HEAD_BYTES // 4), nr, nl)
             assert check(ins) == (60, 4)
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
-        for v, style, strict in ((9, "e32sub", True), (10, "e32sub_nofill", False), (11, "e32all", False), (12, "e64", True), (13, "e32sub_seps", True), (16, "subrev", True)):
+        for v, style, strict in ((9, "e32sub", True), (10, "e32sub_nofill", False), (11, "e32all", False), (12, "e64", True), (13, "e32sub_seps", True), (16, "subrev", True), (18, "vgpreps", True)):
             ins = build(15 - HEAD_BYTES // 4, style=style)
             assert check(ins, strict)[0] == 60 and (not strict or check(ins, strict)[1] == 4), (style, check(ins, strict))
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
