@@ -75,7 +75,9 @@ enum {
                               v_fmaak_f32 literal (-0.3 %) — all of these
                               bit-identical to the product loop.  3..8, 14, 15 = TIMING-ONLY diagnostic loops WITH WRONG
                               RESULTS (no transcendental, no scalar loads, VGPR-sourced operands, an LDS read per source, ...)
-                              that price one part of the loop inside the real kernel; never use them for results. */
+                              that price one part of the loop inside the real kernel; never use them for results.
+                              fp64: 1 = the product loop (VALU instructions at 0 mod 8 bytes), 0 = one 4-byte phase off
+                              (-1.2 %), 2 = eps and 3/8 from VGPR pairs (-0.9 %); other values run form 1. */
 };
 enum { NBODY_VARIANT_AUTO = 0,     /* ISA for the timed arithmetic (fp32, FMA3, blocked or sequential sum), else SMEM */
        NBODY_VARIANT_SMEM = 1,     /* wave-uniform scalar loads (s_load_dwordx16) into SGPRs: no LDS, no VALU cost */

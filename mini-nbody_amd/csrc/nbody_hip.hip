@@ -348,6 +348,7 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   // (measured at N = 16384, 16 workgroups per CU: +4 % with the long buffers; N = 65536, 64 per CU: -2 %)
   a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y < 32LL * cus ? 1 : 0) : g.opt.long_buffers;
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
+    if (g.opt.isa_phase == 2) return launch_timed(L, force_isa_f64<2>, grid, a);
     return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f64<0>, grid, a) : launch_timed(L, force_isa_f64<1>, grid, a);
   }
   if (g.fp64) {

@@ -775,7 +775,12 @@ __global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
   const int groups = (je - jb) / NB_FORCE_LOOP_F64_GROUP;
   if (groups > 0) {
     const uint64_t p = (uint64_t)(uintptr_t)a.src + (uint64_t)jb * sizeof(d4);
-    if constexpr (PLACEMENT == 1) {
+    if constexpr (PLACEMENT == 2) {   // experiment: eps and 3/8 from VGPR pairs instead of SGPR pairs
+      asm volatile(NB_FORCE_LOOP_F64_V2
+                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)
+                   : NB_FORCE_LOOP_F64_CLOBBERS);
+    } else if constexpr (PLACEMENT == 1) {
       asm volatile(NB_FORCE_LOOP_F64_V1
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
                    : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups)

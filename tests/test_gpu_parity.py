@@ -690,6 +690,10 @@ def test_fp64_isa_loop_equals_compiled_kernel(nb, oracle_fast, engine_factory, n
     eng.set_option(nb.OPT_JSUB, 1)
     assert eng.config["variant"] == "isa"
     a = eng.forces(pos)
+    for phase in (0, 2):        # the same loop one placement phase off; the constants from VGPR pairs
+        eng.set_option(nb.OPT_ISA_PHASE, phase)
+        assert np.array_equal(bits(a), bits(eng.forces(pos))), phase
+    eng.set_option(nb.OPT_ISA_PHASE, 1)
     eng.upload(pos, vel)
     eng.step(0.01, 3)
     pa, va = eng.download()

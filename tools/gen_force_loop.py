@@ -334,7 +334,10 @@ def sp(r):
     return "s[%d:%d]" % (r, r + 1)
 
 
-def body_f64(k, sbase, b):
+D_EPSV, D_KV = 46, 48      # experiment (F64_V2): eps and 0.375 in VGPR pairs instead of SGPR pairs
+
+
+def body_f64(k, sbase, b, vconst=False):
     y, yp = D_Y[k & 1], D_Y[(k - 1) & 1]
     dx, dy, dz = D_DSETS[k & 1]
     px, py, pz = D_DSETS[(k - 1) & 1]
@@ -343,7 +346,7 @@ def body_f64(k, sbase, b):
         "v_add_f64 %s, %s, -%s" % (vp(dx), sp(s0), vp(D_XI)),
         "v_add_f64 %s, %s, -%s" % (vp(dy), sp(s0 + 2), vp(D_YI)),
         "v_add_f64 %s, %s, -%s" % (vp(dz), sp(s0 + 4), vp(D_ZI)),
-        "v_fma_f64 %s, %s, %s, %s" % (vp(D_T), vp(dz), vp(dz), sp(D_EPS)),
+        "v_fma_f64 %s, %s, %s, %s" % (vp(D_T), vp(dz), vp(dz), vp(D_EPSV) if vconst else sp(D_EPS)),
         "v_fma_f64 %s, %s, %s, %s" % (vp(D_T), vp(dy), vp(dy), vp(D_T)),
         "v_fma_f64 %s, %s, %s, %s" % (vp(D_T), vp(dx), vp(dx), vp(D_T)),
         "v_rsq_f64_e64 %s, %s" % (vp(y), vp(D_T)),
@@ -355,7 +358,7 @@ def body_f64(k, sbase, b):
     # y <- y + y*e*(1/2 + 3/8 e): the error goes from e0 to (5/16) e0^3, full binary64 from a 2^-24 seed in 5 operations
     out += ["v_mul_f64 %s, %s, %s" % (vp(D_R), vp(D_T), vp(y)),
             "v_fma_f64 %s, -%s, %s, 1.0" % (vp(D_E), vp(D_R), vp(y)),
-            "v_fma_f64 %s, %s, %s, 0.5" % (vp(D_HX), vp(D_E), sp(D_K375)),
+            "v_fma_f64 %s, %s, %s, 0.5" % (vp(D_HX), vp(D_E), vp(D_KV) if vconst else sp(D_K375)),
             "v_mul_f64 %s, %s, %s" % (vp(D_E), vp(D_E), vp(D_HX)),
             "v_fma_f64 %s, %s, %s, %s" % (vp(y), vp(y), vp(D_E), vp(y))]
     out += ["v_mul_f64 %s, %s, %s" % (vp(D_U), vp(y), vp(y)), "v_mul_f64 %s, %s, %s" % (vp(y), vp(y), vp(D_U))]
@@ -366,7 +369,7 @@ F64_PTR, F64_CNT, F64_STRIDE = 68, 70, 71    # the fp64 loop keeps its own scala
 D_K375 = 72                                  # s[72:73] = 0.375 (VOP3 takes no literal on gfx9: the constant lives in an SGPR pair)
 
 
-def build_f64(pad):
+def build_f64(pad, vconst=False):
     px, py, pz = D_DSETS[1]
     ins = [
         "v_mov_b64 %s, %%[xi]" % vp(D_XI), "v_mov_b64 %s, %%[yi]" % vp(D_YI), "v_mov_b64 %s, %%[zi]" % vp(D_ZI),
@@ -378,6 +381,8 @@ def build_f64(pad):
         "s_mov_b32 s%d, 0" % D_K375, "s_mov_b32 s%d, 0x3fd80000" % (D_K375 + 1),
         "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, F64_PTR, F64_PTR + 1),
     ]
+    if vconst:
+        ins += ["v_mov_b64 %s, %s" % (vp(D_EPSV), sp(D_EPS)), "v_mov_b64 %s, %s" % (vp(D_KV), sp(D_K375))]
     ins += ["v_mov_b64 %s, 0" % vp(r) for r in (px, py, pz, D_Y[1])]
     ins.append(".p2align 6")
     ins += ["s_nop 0"] * pad
@@ -385,12 +390,12 @@ def build_f64(pad):
     ins += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s%d, s%d, 1" % (F64_CNT, F64_CNT)]
     ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x40" % (B_BASE, B_BASE + 15, F64_PTR, F64_PTR + 1))
     for b in range(2):
-        ins += body_f64(b, A_BASE, b)
+        ins += body_f64(b, A_BASE, b, vconst)
     ins += ["s_add_u32 s%d, s%d, s%d" % (F64_PTR, F64_PTR, F64_STRIDE), "s_addc_u32 s%d, s%d, 0" % (F64_PTR + 1, F64_PTR + 1)]
     ins += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
     ins.append("s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, F64_PTR, F64_PTR + 1))
     for b in range(2):
-        ins += body_f64(2 + b, B_BASE, b)
+        ins += body_f64(2 + b, B_BASE, b, vconst)
     ins += ["s_cmp_lg_u32 s%d, 0" % F64_CNT, "s_cbranch_scc1 1b"]
     ins += ["v_fma_f64 %s, %s, %s, %s" % (vp(D_AX), vp(px), vp(D_Y[1]), vp(D_AX)),
             "v_fma_f64 %s, %s, %s, %s" % (vp(D_AY), vp(py), vp(D_Y[1]), vp(D_AY)),
@@ -466,9 +471,13 @@ def main():
         clob_long = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in sregs] + ["scc", "memory"]
         f.write("#define NB_FORCE_LOOP_LONG_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob_long))
         f.write("#define NB_FORCE_LOOP_LONG_GROUP %d\n" % GROUP_LONG)
-        for v, pad in ((0, 14), (1, 15)):
+        # fp64 placement (measured with the 17-instruction body, profiles/r02_sweep_fp64_placement.txt): every pad that puts
+        # the VALU instructions at 0 mod 8 bytes gives 1855-1863 G pairs/s at N = 262144, the two tried at 4 mod 8 1832-1840
+        # — the opposite phase to the fp32 loop's.  V1 = the product loop, V0 = one 4-byte phase off.
+        for v, pad in ((0, 15), (1, 14)):
             f.write("#define NB_FORCE_LOOP_F64_V%d \"%s\"\n" % (v, "\\n\\t".join(build_f64(pad))))
-        clob64 = ["v%d" % r for r in range(8, 46)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, D_K375 + 2)] + ["scc", "memory"]
+        f.write("#define NB_FORCE_LOOP_F64_V2 \"%s\"\n" % "\\n\\t".join(build_f64(14, vconst=True)))
+        clob64 = ["v%d" % r for r in range(8, 50)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, D_K375 + 2)] + ["scc", "memory"]
         f.write("#define NB_FORCE_LOOP_F64_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob64))
         f.write("#define NB_FORCE_LOOP_F64_GROUP %d\n" % GROUP_F64)
     n_valu = len([i for i in build(11) if i.startswith("v_")])
