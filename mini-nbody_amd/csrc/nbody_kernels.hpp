@@ -213,13 +213,14 @@ __device__ __forceinline__ void walk_blocks(const ForceArgs& a, int jb, int je, 
 // ---------------------------------------------------------------------------
 // What happens to a finished force (S/compute_store.vhd:203-242 writes {Fx,Fy,Fz,0}; kick and drift are the
 // north_star's bodyForce()/integrate(), one rounding each).
+// (v = the row's velocity word, already loaded: the last arriver of the in-launch combine fetches it together with the
+// partial sums instead of after them)
 template <typename T, typename V4, typename Args>
-__device__ __forceinline__ void apply_force(const Args& a, int i, V4 me, T fx, T fy, T fz) {
+__device__ __forceinline__ void apply_force(const Args& a, int i, V4 me, T fx, T fy, T fz, V4 v) {
   if (a.force_out) { V4 o = {fx, fy, fz, (T)0}; ((V4*)a.force_out)[i] = o; }
   if (a.do_kick) {
     const T dt = sizeof(T) == 8 ? (T)a.dt64 : (T)a.dt;
     V4* vel = (V4*)a.vel;
-    V4 v = vel[i];
     v.x = fma_t(dt, fx, v.x); v.y = fma_t(dt, fy, v.y); v.z = fma_t(dt, fz, v.z);
     vel[i] = v;
     if (a.do_drift) {
@@ -229,6 +230,13 @@ __device__ __forceinline__ void apply_force(const Args& a, int i, V4 me, T fx, T
       ((V4*)a.pos_next_rows)[i] = p;
     }
   }
+}
+
+template <typename T, typename V4, typename Args>
+__device__ __forceinline__ void apply_force(const Args& a, int i, V4 me, T fx, T fy, T fz) {
+  V4 v = me;
+  if (a.do_kick) v = ((const V4*)a.vel)[i];
+  apply_force<T, V4>(a, i, me, fx, fy, fz, v);
 }
 
 // 16-B write-through (sc1) stores and L1-bypassing (sc1) loads of one {x,y,z,w} word through a buffer descriptor:
@@ -272,7 +280,12 @@ __device__ __forceinline__ V4 load_word_sc1(__amdgpu_buffer_rsrc_t rs, int off) 
 // The arguments are re-read here from the kernel-argument segment (every force kernel takes one ForceArgs by value, at
 // offset 0 of it) instead of being kept in SGPRs through the source loop, where the two scalar-load buffers of the
 // delivery need the registers.
-template <typename T, typename V4, int R>
+//
+// CF > 0: partial sums in flight per row in the last arriver's read (default by R).  That read is the tail of a launch —
+// every other wave has left — and it is latency-bound: nseg / CF rounds of ~0.8 us (per-wave timestamps at N = 16384: all
+// source loops over at 62-63 us, the last arrivers done at 70.5 with 8 in flight; profiles/r02_small_n.md).  The kernel's
+// VGPR budget decides how many fit, 4 per partial in fp32 (hipcc splits a 12-byte load into dword loads in three passes).
+template <typename T, typename V4, int R, int CF = 0>
 __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, const V4 (&me)[R], const Sums<T, R>& s) {
   const NB_CONST ForceArgs* ka = (const NB_CONST ForceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ka));   // opaque from here on: the loads below cannot move above the source loop
@@ -318,8 +331,18 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
   // background: the loads below do not depend on it).
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   T fx[R], fy[R], fz[R];
-  constexpr int C = R >= 4 ? 2 : (R == 2 ? 4 : 8);   // partials in flight per row (loads first, then the adds in order); 16 would cost
-                                                      // the hand-scheduled kernel its 7th and 8th resident wave (79 VGPRs), which small N needs
+  // CF > 0 (the hand-scheduled fp32 kernels, which have the registers): the rows' velocities travel with the first round of
+  // partial sums — one memory latency off the launch's tail
+  V4 v0[R];
+  if constexpr (CF > 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane_row + r * kBlock;
+      v0[r] = me[r];
+      if (a.do_kick) v0[r] = ((const V4*)a.vel)[i < row_end ? i : row_end - 1];
+    }
+  }
+  constexpr int C = CF > 0 ? CF : (R >= 4 ? 2 : (R == 2 ? 4 : 8));   // partials in flight per row (loads first, then the adds in order)
   for (int sg0 = 0; sg0 < a.nseg; sg0 += C) {
     V4 p[C][R];
 #pragma unroll
@@ -345,7 +368,10 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = lane_row + r * kBlock;
-    if (i < row_end) apply_force<T, V4>(a, i, me[r], fx[r], fy[r], fz[r]);
+    if (i < row_end) {
+      if constexpr (CF > 0) apply_force<T, V4>(a, i, me[r], fx[r], fy[r], fz[r], v0[r]);
+      else apply_force<T, V4>(a, i, me[r], fx[r], fy[r], fz[r]);
+    }
   }
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -537,7 +563,9 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
   }
   s.ax[0] = ax; s.ay[0] = ay; s.az[0] = az; s.bx[0] = bx; s.by[0] = by; s.bz[0] = bz;
   s.close(blocked, blocked && (count % a.sum_block) != 0);
-  finish_rows<float, f4, 1>(seg, i, row_end, me, s);
+  // partial sums in flight (+ the velocity word): as many as keep the kernel's resident waves — 11 (63 VGPRs, 8 waves per
+  // SIMD) for the product kernel, 13 (71 VGPRs; its SGPRs allow 7 waves) for the long-buffer kernel of small launches
+  finish_rows<float, f4, 1, LONG ? 13 : 11>(seg, i, row_end, me, s);
 }
 template <int PLACEMENT>
 __global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) { force_isa_f32_body<PLACEMENT, 0>(a); }
