@@ -23,8 +23,7 @@ template <typename K> static int time_it(const char* name, K kernel, int wgs, in
     float t; CK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
   }
   std::sort(ms.begin(), ms.end());
-  printf("%-28s workgroups=%6d x %3d threads  median %8.2f us  min %8.2f us  (%.1f ns per workgroup over the 256-workgroup case)\n",
-         name, wgs, threads, ms[ms.size() / 2] * 1e3, ms[0] * 1e3, 0.0);
+  printf("%-28s workgroups=%6d x %3d threads  median %8.2f us  min %8.2f us\n", name, wgs, threads, ms[ms.size() / 2] * 1e3, ms[0] * 1e3);
   CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
   return 0;
 }
