@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", choices=["auto", "ring", "allgather", "direct"], default="auto")
     ap.add_argument("--transport", choices=["auto", "rccl", "host"], default="auto")
+    ap.add_argument("--xcd-map", type=int, default=-1, help="XCD-aware placement of source segments: 1 on, 0 off, -1 the engine's default")
     ap.add_argument("--overlap", type=int, default=1, help="0 gather first, 1 own slice then the rest, 2 one launch per arriving slice")
     args = ap.parse_args()
 
@@ -186,6 +187,8 @@ def main():
     if args.sum_block > 0:
         eng.set_option(nb.OPT_SUM_BLOCK, args.sum_block)
     eng.set_option(nb.OPT_FUSE_COMBINE, args.fuse)
+    if args.xcd_map >= 0:
+        eng.set_option(nb.OPT_XCD_MAP, args.xcd_map)
     eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER, "direct": nb.COMM_DIRECT}[args.comm])
     eng.set_option(nb.OPT_OVERLAP, args.overlap)
     import numpy as np

@@ -59,6 +59,10 @@ enum {
                               arrived slices (default); 2 = one launch per arriving slice, each released by that slice's
                               event; 0 = gather first, one launch */
   NBODY_OPT_SUM_BLOCK = 13, /* NBODY_SUM_BLOCKED: sources per level-1 block (multiple of 64; default 1024) */
+  NBODY_OPT_XCD_MAP = 16,  /* 1: workgroups that share an XCD take the same source segments (launches with a multiple of 8 segment
+                              rows), so each XCD's L2 fetches its segments once; 0: (blockIdx.x, blockIdx.y) = (row block, segment);
+                              -1 (default): on for launches of >= 4096 row blocks (N = 1M: -39 % memory-side traffic at level time;
+                              smaller launches measured slower with it).  Same results either way. */
   NBODY_OPT_ISA_LONG_BUFFERS = 15, /* NBODY_VARIANT_ISA: scalar buffers of 8 bodies instead of 4 (-1 = auto: when a launch has fewer
                               than 32 workgroups per CU; 0, 1 = force).  Same bits either way. */
   NBODY_OPT_FUSE_COMBINE = 14, /* 1: the segments' partial sums are added by the last wave to arrive, inside the force launch (one

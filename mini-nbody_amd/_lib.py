@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libnbody_hip.so")
 
 # mirrors of the enums in include/nbody.h
 (OPT_VARIANT, OPT_IBLOCK, OPT_JSUB, OPT_JSLICES, OPT_ARITH, OPT_SUM_ORDER, OPT_TIMING, OPT_COMM, OPT_OVERLAP, OPT_ISA_PHASE,
- OPT_WAVES_PER_SIMD, OPT_GRAPH, OPT_SUM_BLOCK, OPT_FUSE_COMBINE, OPT_ISA_LONG_BUFFERS) = range(1, 16)
+ OPT_WAVES_PER_SIMD, OPT_GRAPH, OPT_SUM_BLOCK, OPT_FUSE_COMBINE, OPT_ISA_LONG_BUFFERS, OPT_XCD_MAP) = range(1, 17)
 VARIANT_AUTO, VARIANT_SMEM, VARIANT_LDS, VARIANT_READLANE, VARIANT_ISA = range(5)
 ARITH_FMA3, ARITH_REFERENCE, ARITH_STRICT, ARITH_REFERENCE_STRICT = 0, 1, 2, 3
 SUM_SEQ, SUM_FPGA16, SUM_BLOCKED = 0, 1, 2

@@ -102,7 +102,7 @@ struct Local {
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
   int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_BLOCKED, sum_block = 1024, fuse = -1;
-  int timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1, long_buffers = -1;
+  int timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1, long_buffers = -1, xcd_map = -1;
 };
 
 // what happens to the force of a row once all its segments are summed
@@ -346,6 +346,10 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   // few workgroups per CU = few waves per SIMD and short segments: the scalar loads are no longer hidden by other waves
   const int cus = g.cu_count > 0 ? g.cu_count : 256;
   // (measured at N = 16384, 16 workgroups per CU: +4 % with the long buffers; N = 65536, 64 per CU: -2 %)
+  // XCD-aware placement of segments (block_segment): needs a multiple of 8 segment rows in the launch.  Automatic: for
+  // launches of >= 4096 row blocks (N = 1M on one GPU: sources fetched once per XCD, 477 MB of memory-side traffic per step
+  // instead of 788, time level); with fewer row blocks it measured slower (N = 262144: -2 %, N = 16384: -18 %)
+  a.xcd_map = ((g.opt.xcd_map > 0 || (g.opt.xcd_map < 0 && grid.x >= 4096)) && grid.y % 8 == 0) ? 1 : 0;
   a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y < 32LL * cus ? 1 : 0) : g.opt.long_buffers;
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
     if (g.opt.isa_phase == 2) return launch_timed(L, force_isa_f64<2>, grid, a);
@@ -1026,6 +1030,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_SUM_BLOCK: if (value < 8 || value > (1 << 24) || value % 64) return NBODY_ERR_ARG; g.opt.sum_block = value; break;
     case NBODY_OPT_FUSE_COMBINE: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.fuse = value; break;
     case NBODY_OPT_ISA_LONG_BUFFERS: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.long_buffers = value; break;
+    case NBODY_OPT_XCD_MAP: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.xcd_map = value; break;
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
     case NBODY_OPT_COMM: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;

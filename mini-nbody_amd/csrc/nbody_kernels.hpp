@@ -74,6 +74,7 @@ struct ForceArgs {
   int do_kick, do_drift;  // what to do with the finished force: v += dt*F, then r' = r + v*dt
   int sum_block;        // K sources per level-1 block; 0 = one sequential sum per segment
   int long_buffers;     // ISA variant: 8-body scalar buffers (launches with < 4 waves per SIMD, see tools/gen_force_loop.py)
+  int xcd_map;          // 1: workgroups that share an XCD (linear id mod 8) take the same source segments, see block_segment()
   int fpga16;           // 1: S/fxyz.vhd:129-184 + S/final_adder.vhd:88-104 summation order inside a segment
   float dt;
   double dt64;
@@ -239,6 +240,20 @@ __device__ __forceinline__ void apply_force(const Args& a, int i, V4 me, T fx, T
   apply_force<T, V4>(a, i, me, fx, fy, fz, v);
 }
 
+// (row block, segment row) of this workgroup: see block_segment() for the XCD-aware mapping
+template <typename Args>   // ForceArgs by value or in the kernel-argument segment
+__device__ __forceinline__ void wg_coords(const Args& a, int* rb, int* y) {
+  *y = blockIdx.y;
+  *rb = blockIdx.x;
+  if (a.xcd_map) {   // the host sets it only when gridDim.y % 8 == 0
+    const unsigned X = gridDim.x;
+    const unsigned linear = blockIdx.y * X + blockIdx.x, slot = linear >> 3;
+    const unsigned m = slot / X;
+    *y = (int)((linear & 7u) + 8u * m);
+    *rb = (int)(slot - m * X);
+  }
+}
+
 // 16-B write-through (sc1) stores and L1-bypassing (sc1) loads of one {x,y,z,w} word through a buffer descriptor:
 // the hand-off between workgroups below moves its payload with nothing else (MI355X_MICROARCH.md, inter-workgroup
 // visibility: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by other CUs' stores).
@@ -308,7 +323,9 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wg_row0 = a.row0 + blockIdx.x * (kBlock * R);            // wave-uniform: first row of this workgroup
+  int row_block, y_unused;
+  wg_coords(a, &row_block, &y_unused);   // recomputed from the re-read arguments rather than kept in SGPRs through the source loop
+  const int wg_row0 = a.row0 + row_block * (kBlock * R);             // wave-uniform: first row of this workgroup
   const int wg_rows = min(kBlock * R, row_end - wg_row0);
   const int lane_off = (int)(threadIdx.x * sizeof(V4));
   {
@@ -321,7 +338,7 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached memory before its ticket is taken
-  unsigned* ticket = a.tickets + (size_t)blockIdx.x * 4 + wave;
+  unsigned* ticket = a.tickets + (size_t)row_block * 4 + wave;
   unsigned t = 0;
   if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
@@ -376,8 +393,17 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void block_segment(const ForceArgs& a, int* seg, int* jb, int* je) {
-  int y = blockIdx.y;
+// Which rows and which source segment a workgroup takes.  The hardware deals workgroups round-robin over the 8 XCDs in
+// launch order (blocks b and b + 8 share one; MI355X_MICROARCH.md "Workgroup dispatch, XCD placement"; checked here with
+// HW_REG_XCC_ID), and each XCD has its own 4 MiB L2.  With the plain (blockIdx.x, blockIdx.y) = (row block, segment)
+// mapping all 8 XCDs walk the same segment at the same time and each pulls it over the fabric: N = 1M, 8 segments of
+// 2 MiB, 16 resident sets -> 268 MB of source reads per step for 16 MiB of sources.  xcd_map (when the launch has a
+// multiple of 8 segment rows): XCD x takes the segment rows y = x (mod 8) for every row block, in launch order
+// slot = linear / 8 -> (y = x + 8 * (slot / X), row block = slot % X): its resident workgroups read ONE segment, from its
+// own L2, fetched once.  Only who computes what changes; sums, tickets and results are the same.
+__device__ __forceinline__ void block_segment(const ForceArgs& a, int* seg, int* jb, int* je, int* rb) {
+  int y;
+  wg_coords(a, rb, &y);
   int q = a.slice_start - y / a.sub;
   q %= a.nslices; if (q < 0) q += a.nslices;
   int t = y % a.sub;
@@ -404,10 +430,10 @@ __device__ __forceinline__ void load_rows(const ForceArgs& a, int lane_row, int 
 // broadcast.  Groups are double-buffered by hand (load group g+1, compute g).
 template <int R, int ARITH>
 __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
-  int seg, jb, je;
-  block_segment(a, &seg, &jb, &je);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
   const float eps = soft_f32();
-  const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
+  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[R];
   load_rows<float, f4, R>(a, lane_row, row_end, me);
@@ -462,10 +488,10 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
 // which is why it is a kernel of its own.
 template <int PLACEMENT, int LONG>
 __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
-  int seg, jb, je;
-  block_segment(a, &seg, &jb, &je);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
   const float eps = soft_f32();
-  const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
+  const int i = a.row0 + rb * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
   const int count = je - jb;
@@ -582,11 +608,11 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
   static_assert(TILE % kBlock == 0, "tile is a multiple of the workgroup");
   constexpr int LPT = TILE / kBlock;   // loads per thread per tile
   __shared__ f4 tile[2][TILE];
-  int seg, jb, je;
-  block_segment(a, &seg, &jb, &je);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
   const float eps = soft_f32();
   const f4* src = (const f4*)a.src;
-  const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
+  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[R];
   load_rows<float, f4, R>(a, lane_row, row_end, me);
@@ -648,12 +674,12 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
 // amortised over the R bodies of the lane.
 template <int R, int ARITH>
 __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
-  int seg, jb, je;
-  block_segment(a, &seg, &jb, &je);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
   const float eps = soft_f32();
   const f4* src = (const f4*)a.src;
   const int lane = threadIdx.x & 63;
-  const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
+  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[R];
   load_rows<float, f4, R>(a, lane_row, row_end, me);
@@ -702,10 +728,10 @@ __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
 // lane; 48 accumulators live in VGPRs.  A study mode, not the timed path.
 template <int ARITH>
 __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
-  int seg, jb, je;
-  block_segment(a, &seg, &jb, &je);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
   const float eps = soft_f32();
-  const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
+  const int i = a.row0 + rb * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[1];
   load_rows<float, f4, 1>(a, i, row_end, me);
@@ -754,10 +780,10 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
 // bits than the 1e-5 target needs; sum_block is ignored).
 template <int R>
 __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
-  int seg, jb, je;
-  block_segment(a, &seg, &jb, &je);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
   const double eps = (double)soft_f32();
-  const int lane_row = a.row0 + blockIdx.x * (kBlock * R) + threadIdx.x;
+  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   d4 me[R];
   load_rows<double, d4, R>(a, lane_row, row_end, me);
@@ -790,10 +816,10 @@ __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
 // per iteration, every instruction 8 bytes (v_rsq_f64 in its _e64 encoding).  Same bits as force_smem_f64<1>.
 template <int PLACEMENT>
 __global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
-  int seg, jb, je;
-  block_segment(a, &seg, &jb, &je);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
   const double eps = (double)soft_f32();
-  const int i = a.row0 + blockIdx.x * kBlock + threadIdx.x;
+  const int i = a.row0 + rb * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   d4 me[1];
   load_rows<double, d4, 1>(a, i, row_end, me);

@@ -220,6 +220,50 @@ def test_segmentation_matches_host_mirror_bitwise(nb, oracle_fast, engine_factor
         assert np.array_equal(bits(got), bits(oracle_forces(oracle_fast, eng, pos))), (nsl, sub)
 
 
+def test_xcd_aware_segment_placement_changes_no_bit(nb, oracle_fast, engine_factory, monkeypatch):
+    """NBODY_OPT_XCD_MAP (default on for launches with a multiple of 8 segment rows): workgroups that share an XCD take
+    the same source segments, so each XCD's L2 fetches them once (block_segment in nbody_kernels.hpp).  Only who computes
+    what changes: forces, steps (both launch forms), row windows and the 8-virtual-rank schedule give the bits of the plain
+    (blockIdx.x, blockIdx.y) placement, for every delivery variant, ragged sizes and fp64."""
+    for n, fp64 in ((257, False), (5000, False), (20000, False), (70001, False), (5000, True)):
+        dtype = np.float64 if fp64 else np.float32
+        pos, vel = nb.make_bodies(n, seed=3 * n, dtype=dtype)
+        eng = engine_factory(n, fp64=fp64)
+        shapes = (("auto", 0, 8, 1), ("auto", 0, 64, 1), ("auto", 0, 3, 8), ("smem", 2, 16, 1), ("lds", 1, 8, 2), ("readlane", 2, 8, 1))
+        for variant, iblock, jsub, jsl in shapes if not fp64 else shapes[:3]:
+            for fuse in (1, 0):
+                out = {}
+                for xcd in (1, 0):
+                    set_variant(nb, eng, variant, iblock, jsub=jsub, jslices=jsl)
+                    eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+                    eng.set_option(nb.OPT_XCD_MAP, xcd)
+                    f = eng.forces(pos)
+                    eng.upload(pos, vel)
+                    w = eng.forces_rows(n // 3, min(300, n - n // 3))
+                    eng.step(0.01, 7)
+                    out[xcd] = (f, w) + eng.download()
+                for x, y in zip(out[1], out[0]):
+                    assert np.array_equal(bits(x), bits(y)), (n, fp64, variant, iblock, jsub, jsl, fuse)
+        if not fp64 and n == 20000:     # and it is what the oracle says, in the engine's order
+            set_variant(nb, eng, "auto", 0, jsub=8, jslices=1)
+            eng.set_option(nb.OPT_XCD_MAP, 1)
+            eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+            assert np.array_equal(bits(eng.forces(pos)), bits(oracle_forces(oracle_fast, eng, pos)))
+    # the multi-GPU schedule on 8 virtual ranks: own-slice launch (8 segment rows) + the launch over the 7 others (56)
+    monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
+    n = 40000
+    pos, vel = nb.make_bodies(n, seed=11)
+    out = {}
+    for xcd in (1, 0):
+        eng = engine_factory(n, ngpus=8)
+        eng.set_option(nb.OPT_XCD_MAP, xcd)
+        assert eng.config["nseg"] % 8 == 0
+        eng.upload(pos, vel)
+        eng.step(0.01, 5)
+        out[xcd] = eng.download()
+    assert np.array_equal(bits(out[1][0]), bits(out[0][0])) and np.array_equal(bits(out[1][1]), bits(out[0][1]))
+
+
 def test_one_launch_combine_equals_combine_kernel(nb, engine_factory):
     """The in-launch combine (last-arriving workgroup adds the partial sums, finish_rows in nbody_kernels.hpp) against the
     two-launch form (combine_kernel): same bits for every variant and shape, and over many steps — the partial buffers are
