@@ -117,6 +117,7 @@ struct Global {
   // HIP graph of TWO consecutive steps (the position buffers swap every step, so a pair returns to the same state):
   // replayed by nbody_step when one GPU runs many short steps (launch-bound regime)
   hipGraphExec_t step_graph = nullptr;
+  bool stepped_eagerly = false;   // a step has been launched outside a capture since nbody_init
   float graph_dt = 0.f; double graph_dt64 = 0.0; int graph_cur = -1;
   bool init = false;
   int n = 0, fp64 = 0, tile = 256;
@@ -612,7 +613,7 @@ int init_common(int n, int fp64, int tile) {
   if (tile == 0) tile = 256;
   if (tile < 64 || tile > 1024 || tile % 64) return NBODY_ERR_ARG;
   g.n = n; g.fp64 = fp64 ? 1 : 0; g.tile = tile;
-  g.steps_done = 0;
+  g.steps_done = 0; g.stepped_eagerly = false;
   return NBODY_OK;
 }
 
@@ -724,6 +725,11 @@ int step_impl(float dt, double dt64, int nsteps) {
   if (g.opt.graph && g.nranks == 1 && g.nlocal == 1 && !g.opt.timing && nsteps >= 4) {
     Local& L = g.loc[0];
     HIPC(hipSetDevice(L.device));
+    // A graph captured before the step's kernels have ever really run replays slower for good — measured at N = 4096:
+    // 15.1 us per step when the capture is the first thing after nbody_upload, 13.1 us when one eager step came first,
+    // whichever buffer is current and however often the graph is reused (profiles/r02_small_n.md).  So the first step of
+    // an engine's life is always launched eagerly.
+    if (!g.stepped_eagerly) { NBC(enqueue_step(dt, dt64)); ++s; g.stepped_eagerly = true; }
     if (!g.step_graph || g.graph_cur != L.cur || g.graph_dt != dt || g.graph_dt64 != dt64) {
       drop_step_graph();
       hipGraph_t graph = nullptr;
@@ -745,6 +751,7 @@ int step_impl(float dt, double dt64, int nsteps) {
     }
     for (; s + 2 <= nsteps; s += 2) { HIPC(hipGraphLaunch(g.step_graph, L.compute)); g.steps_done += 2; }
   }
+  if (s < nsteps) g.stepped_eagerly = true;
   for (; s < nsteps; ++s) NBC(enqueue_step(dt, dt64));
   return NBODY_OK;
 }
