@@ -12,6 +12,13 @@ configuration the metric is quoted on); with N GPUs the same N is sharded by bod
 the positions travel by RCCL inside libnbody_hip.so.  torch is used for the rendezvous, the barrier,
 the max-over-ranks and torch.cuda.synchronize() only.  `--fp64 --bodies 4194304` is BASELINE configs[4].
 
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts and SUPERVISES its own N
+worker processes (one per GPU; the parent never touches a GPU); under torch.distributed.run every rank process supervises
+its own worker and the N supervisors agree through a directory under /tmp.  A worker that fails, or a job that passes
+--deadline seconds (an RCCL hang has no other symptom), is killed and the job is started once more with --transport host
+(positions staged through host memory and torch.distributed); the line then says so in config.comm.  Workers run the
+library's transport self-test (nbody_comm_selftest: every received word checked) before the warm-up.
+
 Rank 0 prints ONE JSON line, always with:
   roofline      the force kernel priced at 20 flop per pair against the fp32 (157.3 TFLOP/s) or
                 fp64 (78.6) VECTOR peak — the path has no contraction for the matrix cores — with the kernel's
@@ -22,12 +29,17 @@ Rank 0 prints ONE JSON line, always with:
                 configuration equals the run's; otherwise `traffic` is null.
   cpu_baseline  the oracle (oracle/nbody_ref.c, kind "port": the reference is VHDL and has no CPU path) timed on
                 this box's host cores, rank 0, after the timed region, on a bounded row sample.
+and for N > 1: comm_exposed_ms_per_step — how long per step the compute stream sat waiting for arriving position slices
+(HIP events around every such wait; 0 = the transfers hid behind the own-slice kernel).
 """
 import argparse
 import glob
 import importlib
 import json
 import os
+import shutil
+import signal
+import socket
 import subprocess
 import sys
 import tempfile
@@ -44,6 +56,7 @@ PEAK_VECTOR_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X_MICROARCH.md: 256 CU
 # measured: profiles/r01_microbench_valu_issue.txt, DESIGN.md §3
 ISSUE_CYCLES_PER_WAVE_PAIR = {"f32": 30, "f64": 80}
 METRIC = "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofline"
+COMM_NAMES = {0: "ring", 1: "allgather", 2: "auto", 3: "direct"}
 
 
 def cpu_baseline(n, seed, fp64):
@@ -121,7 +134,204 @@ def matching_pmc(run_cfg):
     return None
 
 
-def main():
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Supervision of the worker processes.  Nothing in this section imports torch or touches a GPU.
+WORKER_ENV = "NBODY_BENCH_WORKER"
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def kill_group(proc, grace=5.0):
+    """end exactly the process group this supervisor started (start_new_session), never a pattern"""
+    if proc.poll() is not None:
+        return
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            return
+        t0 = time.time()
+        while time.time() - t0 < grace:
+            if proc.poll() is not None:
+                return
+            time.sleep(0.05)
+
+
+def tail(path, n=600):
+    try:
+        return open(path, errors="replace").read()[-n:].strip().replace("\n", " | ")
+    except OSError:
+        return ""
+
+
+def start_worker(cmd, rank, local, world, port, transport, logdir, attempt, extra_env=None):
+    env = dict(os.environ)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(local), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), WORKER_ENV: "1",
+                "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    # the workers hold their own rendezvous (rank 0 hosts the store on `port`), whatever launched the supervisors
+    for k in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+        env.pop(k, None)
+    env.pop("OMP_NUM_THREADS", None)      # torch.distributed.run pins it to 1; the CPU-baseline leg wants the host's cores
+    if extra_env:
+        env.update(extra_env)
+    out = open(os.path.join(logdir, "a%d_rank%d.out" % (attempt, rank)), "w")
+    err = open(os.path.join(logdir, "a%d_rank%d.err" % (attempt, rank)), "w")
+    full = list(cmd) + (["--transport", transport] if transport else [])
+    return subprocess.Popen(full, env=env, stdout=out, stderr=err, start_new_session=True), out.name, err.name
+
+
+def wait_workers(procs, deadline_s, peers_failed=lambda: None, poll=0.1):
+    """-> None when every worker exited 0, else a reason string.  peers_failed() lets sibling supervisors report."""
+    t0 = time.time()
+    while True:
+        codes = [p.poll() for p, _, _ in procs]
+        bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            i, c = bad[0]
+            return "worker exited with code %d: %s" % (c, tail(procs[i][2]) or tail(procs[i][1]))
+        if all(c == 0 for c in codes):
+            return None
+        why = peers_failed()
+        if why:
+            return why
+        if time.time() - t0 > deadline_s:
+            return "timed out after %.0f s" % deadline_s
+        time.sleep(poll)
+
+
+def json_line(path):
+    try:
+        lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    except (OSError, ValueError):
+        return None
+
+
+def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None, log=sys.stderr, extra_env=None):
+    """Run the job as `world` worker processes, of which this supervisor owns `my_ranks` (all of them when it was started
+    bare; one when torch.distributed.run started one supervisor per rank — then rdzv_dir, shared by the supervisors, carries
+    the worker port and every supervisor's verdict on an attempt).  Attempt 0 uses `transport`; if a worker fails or the
+    deadline passes, everything is killed and attempt 1 runs with --transport host.  Returns (exit code, JSON object of
+    rank 0's line or None)."""
+    logdir = tempfile.mkdtemp(prefix="nbody_bench_logs_")
+    lead = 0 in my_ranks
+    first_reason = None
+    attempts = [transport] + (["host"] if transport != "host" else [])
+    try:
+        for attempt, tr in enumerate(attempts):
+            # ---- the workers' rendezvous port: chosen by the supervisor of rank 0, published through rdzv_dir
+            if rdzv_dir is None:
+                port = free_port()
+            else:
+                pfile = os.path.join(rdzv_dir, "port.%d" % attempt)
+                if lead:
+                    port = free_port()
+                    with open(pfile + ".tmp", "w") as f:
+                        f.write(str(port))
+                    os.replace(pfile + ".tmp", pfile)
+                else:
+                    t0 = time.time()
+                    while not os.path.exists(pfile):
+                        if time.time() - t0 > deadline_s:
+                            return 1, None
+                        time.sleep(0.05)
+                    port = int(open(pfile).read())
+            procs = [start_worker(worker_cmd, r, r, world, port, tr, logdir, attempt, extra_env) for r in my_ranks]
+
+            def peers_failed():
+                if rdzv_dir is None:
+                    return None
+                for f in glob.glob(os.path.join(rdzv_dir, "verdict.%d.*" % attempt)):
+                    if f.endswith(".tmp"):
+                        continue
+                    try:
+                        txt = open(f).read()
+                    except OSError:
+                        continue
+                    if txt and not txt.startswith("ok") and not txt.startswith("a peer supervisor reported"):
+                        return "a peer supervisor reported: " + txt
+                return None
+
+            reason = wait_workers(procs, deadline_s, peers_failed)
+            if rdzv_dir is not None:
+                for r in my_ranks:      # this supervisor's verdict, then everybody's
+                    vf = os.path.join(rdzv_dir, "verdict.%d.%d" % (attempt, r))
+                    with open(vf + ".tmp", "w") as f:
+                        f.write("ok" if reason is None else reason)
+                    os.replace(vf + ".tmp", vf)
+                t0 = time.time()
+                while reason is None:
+                    files = glob.glob(os.path.join(rdzv_dir, "verdict.%d.*" % attempt))
+                    reason = peers_failed()
+                    if len([f for f in files if not f.endswith(".tmp")]) >= world or reason:
+                        break
+                    if time.time() - t0 > deadline_s:
+                        reason = "peer supervisors did not report within %.0f s" % deadline_s
+                    time.sleep(0.05)
+            for p, _, _ in procs:
+                kill_group(p)
+            if reason is None:
+                obj = json_line(procs[0][1]) if lead else None
+                if lead and obj is None:
+                    reason = "rank 0 printed no JSON line: " + tail(procs[0][2])
+                else:
+                    if obj is not None and first_reason is not None:
+                        obj.setdefault("config", {})["comm"] = "%s (rccl attempt: %s)" % (obj.get("config", {}).get("comm"), first_reason)
+                    return 0, obj
+            print("[bench supervisor] attempt %d (--transport %s) failed: %s" % (attempt, tr, reason), file=log, flush=True)
+            if first_reason is None:
+                first_reason = reason[:300]
+        return 1, None
+    finally:
+        shutil.rmtree(logdir, ignore_errors=True)
+
+
+def supervisor_main(args, argv):
+    """-> exit code, or None when this process should run the benchmark itself (one GPU, or it IS a worker)."""
+    if os.environ.get(WORKER_ENV) or args.gpus <= 1:
+        return None
+    world_env = os.environ.get("WORLD_SIZE")
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--no-supervise"]
+    # drop a --transport given on the command line: the supervisor passes the one of the attempt
+    clean = []
+    skip = False
+    for a in cmd:
+        if skip:
+            skip = False
+            continue
+        if a == "--transport":
+            skip = True
+            continue
+        if a.startswith("--transport="):
+            continue
+        clean.append(a)
+    if world_env is None:
+        code, obj = supervise(clean, args.gpus, list(range(args.gpus)), args.transport, args.deadline)
+    else:
+        world = int(world_env)
+        if world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        rank = int(os.environ.get("RANK", "0"))
+        # every supervisor of this job has the same parent (the torch.distributed.run agent) and the same MASTER_PORT
+        rdzv = os.path.join(tempfile.gettempdir(), "nbody_bench_rdzv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        os.makedirs(rdzv, exist_ok=True)
+        code, obj = supervise(clean, world, [rank], args.transport, args.deadline, rdzv_dir=rdzv)
+        if rank == 0:
+            time.sleep(0.5)
+            shutil.rmtree(rdzv, ignore_errors=True)
+    if obj is not None:
+        print(json.dumps(obj), flush=True)
+    return code
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -142,7 +352,16 @@ def main():
     ap.add_argument("--transport", choices=["auto", "rccl", "host"], default="auto")
     ap.add_argument("--xcd-map", type=int, default=-1, help="XCD-aware placement of source segments: 1 on, 0 off, -1 the engine's default")
     ap.add_argument("--overlap", type=int, default=1, help="0 gather first, 1 own slice then the rest, 2 one launch per arriving slice")
-    args = ap.parse_args()
+    ap.add_argument("--wsplit", type=int, default=-1, help="4: 64-row workgroups whose waves split the segment, 1: round 2's layout, -1: the engine's choice")
+    ap.add_argument("--events", choices=["auto", "inline", "separate"], default="auto",
+                    help="HIP events around every force kernel inside the timed region (inline), or the timed region on the path "
+                         "nbody_step() users get (HIP-graph replay, no events) and the kernel duration from a second pass (separate); "
+                         "auto: separate when a step is short (one rank's share < 1e10 pairs), where events would change the path")
+    ap.add_argument("--deadline", type=float, default=420.0, help="N > 1: seconds a supervised attempt may take before it is killed and retried on the host transport")
+    args = ap.parse_args(argv)
+    code = supervisor_main(args, argv)
+    if code is not None:
+        raise SystemExit(code)
 
     if not os.path.exists(os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so")):
         # fresh checkout (built files are git-ignored): build the HIP library; a failure is fatal, there is no fallback
@@ -160,8 +379,6 @@ def main():
 
     rank, world, local = D.env_rank()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -191,15 +408,24 @@ def main():
         eng.set_option(nb.OPT_XCD_MAP, args.xcd_map)
     eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER, "direct": nb.COMM_DIRECT}[args.comm])
     eng.set_option(nb.OPT_OVERLAP, args.overlap)
+    eng.set_option(nb.OPT_WSPLIT, args.wsplit)
+    transport = getattr(eng, "transport", "rccl") if world > 1 else None
+    if world > 1 and transport == "rccl":
+        # every word of a patterned all-gather checked, in the form the steps will use, before anything is timed; a failure
+        # ends this worker with a non-zero code and the supervisor starts the job again on the host transport
+        eng.comm_selftest()
     import numpy as np
     pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
     eng.upload(pos, vel)                      # inputs resident in HBM before the timed region
     dt = 0.01
 
+    share = float(n) * float(n) / world
+    inline = args.events == "inline" or (args.events == "auto" and share >= 1e10)
     eng.step(dt, args.warmup)
     eng.sync()
-    eng.set_option(nb.OPT_TIMING, 1)
+    eng.set_option(nb.OPT_TIMING, 1 if inline else 0)
     eng.kernel_time(reset=True)
+    eng.comm_time(reset=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -208,11 +434,22 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_steps = args.steps
+    if not inline:
+        # the timed region ran the path nbody_step() users get (one GPU: HIP-graph replay); the kernel's duration comes from
+        # a second pass with events around every launch
+        kernel_steps = min(args.steps, 50)
+        eng.set_option(nb.OPT_TIMING, 1)
+        eng.kernel_time(reset=True)
+        eng.comm_time(reset=True)
+        eng.step(dt, kernel_steps)
+        eng.sync()
     kernel_ms, launches = eng.kernel_time(reset=True)
+    wait_ms, waits = eng.comm_time(reset=True)
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
+        t = torch.tensor([elapsed, kernel_ms, wait_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        elapsed, kernel_ms, wait_ms = float(t[0]), float(t[1]), float(t[2])
     cfg = eng.config
     # sanity of the state the timed steps produced: this rank's own slice, without any collective (nothing after the
     # timed region may stall the report)
@@ -225,7 +462,7 @@ def main():
         value = pairs_per_step * args.steps / elapsed / 1e9
         n_local = cfg["n_local"]
         # force kernel: per launch this rank's share of the pairs; duration from HIP events on the compute stream
-        launches_per_step = max(1, launches // max(1, args.steps))
+        launches_per_step = max(1, launches // max(1, kernel_steps))
         pairs_per_launch = float(n_local) * float(n) / launches_per_step
         avg_launch_s = kernel_ms * 1e-3 / max(1, launches)
         kernel_rate = pairs_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0   # pairs/s on one GPU
@@ -237,6 +474,7 @@ def main():
         wave_pairs_per_launch = pairs_per_launch / 64.0
         run_cfg = {"n": n, "dtype": dtype, "n_gpus": world, "variant": cfg["variant"], "iblock": cfg["iblock"], "nseg": cfg["nseg"],
                    "sum_order": cfg["sum_order"], "sum_block": cfg["sum_block"], "launches_per_step": cfg["launches_per_step"],
+                   "wsplit": cfg["wsplit"], "isa_phase": cfg["isa_phase"], "long_buffers": cfg["long_buffers"], "xcd_map": cfg["xcd_map"],
                    "kernel_source_sha": kernel_source_sha()}
         roof = {"bound": "valu", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / peak, 4), "traffic": None, "flop_per_pair": FLOP_PER_PAIR,
@@ -248,6 +486,7 @@ def main():
                 "issue_bound_gpairs_per_s": round(issue_bound / 1e9, 1),
                 "frac_of_issue_bound": round(kernel_rate / issue_bound, 4) if issue_bound else None,
                 "cycles_per_wave_pair_at_nominal_clock": round(avg_launch_s * clk * simds / wave_pairs_per_launch, 2) if wave_pairs_per_launch else None,
+                "kernel_events": "inline (inside the timed region)" if inline else "separate pass of %d steps after the timed region (the timed region ran without events%s)" % (kernel_steps, ", HIP-graph replay" if world == 1 else ""),
                 "note": "VALU-issue-bound: per pair 11 full-rate + 1 quarter-rate instruction in fp32 (30 cycles per wave64), "
                         "16 + 1 in fp64 (80); neither HBM nor MFMA bounds it (no contraction; HBM traffic is 64 B per body per step)"}
         pj = matching_pmc(run_cfg)
@@ -258,7 +497,13 @@ def main():
                            "cycles_per_wave_pair": round(pj.get("cycles_per_wave_pair", 0.0), 2),
                            "hbm_gb_per_s": round(pj.get("hbm_gb_per_s", 0.0), 2),
                            "hbm_frac_of_peak": round(pj.get("hbm_frac_of_8tbs", 0.0), 5),
-                           "kernel_ms_avg_trace": pj.get("force_kernel_avg_ms_trace")}
+                           "kernel_ms_avg_trace": pj.get("force_kernel_avg_ms_trace"),
+                           # "VALU-busy" as the north_star means it: (sum over the VALU instructions a wave issues for one pair of
+                           # their issue cycles: 11 x 2 + 8 in fp32, 16 x 4 + 16 in fp64, profiles/r01_microbench_valu_issue.txt)
+                           # / the SIMD cycles the kernel actually took per wave-pair (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / wave-pairs)
+                           "valu_issue_busy": round(ISSUE_CYCLES_PER_WAVE_PAIR[dtype] / pj["cycles_per_wave_pair"], 4) if pj.get("cycles_per_wave_pair") else None,
+                           "valu_issue_busy_formula": "(11 x 2 + 8 | 16 x 4 + 16 issue cycles per wave-pair) / measured SIMD cycles per wave-pair",
+                           "sq_active_inst_valu_over_busy_cycles": pj.get("sq_valu_busy")}
         out = {
             "metric": METRIC if (n == (1 << 20) and not args.fp64) else "billion pair-interactions/s at N=%d %s" % (n, "fp64" if args.fp64 else "fp32"),
             "value": round(value, 2), "unit": "billion pair-interactions/s", "n_gpus": world, "steps": args.steps,
@@ -267,10 +512,16 @@ def main():
             "config": {"workload": "N=%d %s all-pairs softened gravity, leapfrog kick-drift, dt=0.01, seed %d"
                                    % (n, "fp64" if args.fp64 else "fp32", args.seed),
                        "n_bodies": n, "pairs_per_step": pairs_per_step, "parallelism": "bodies sharded over %d GPU(s)" % world,
-                       "kernel": cfg, "kernel_source_sha": kernel_source_sha(), "comm": (args.comm + " / " + getattr(eng, "transport", "rccl") + " / overlap %d" % args.overlap) if world > 1 else None,
+                       "kernel": cfg, "kernel_source_sha": kernel_source_sha(),
+                       "comm": ("%s / %s / overlap %d / stream priority %d" % (COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?"), transport, args.overlap,
+                                                                        eng.info(nb._lib.INFO_COMM_PRIORITY))) if world > 1 else None,
+                       "graph_replay": bool(world == 1 and not inline and args.steps >= 4),
                        "finite": finite},
             "roofline": roof,
         }
+        if world > 1:
+            out["comm_exposed_ms_per_step"] = round(wait_ms / max(1, kernel_steps), 4)
+            out["comm_waits_per_step"] = round(waits / max(1, kernel_steps), 2)
     eng.close()
     if rank == 0:
         if not args.no_cpu_baseline:

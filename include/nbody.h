@@ -70,18 +70,21 @@ enum {
                               >= 4 workgroups per CU, where the hand-off hides behind other workgroups, else two.  Same bits. */
   NBODY_OPT_GRAPH = 12,    /* 1 (default): nbody_step on one GPU replays a HIP graph of two steps; 0: launch every kernel */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
+  NBODY_OPT_WSPLIT = 17,   /* 4: a workgroup owns 64 bodies and its four waves walk a quarter of the source segment each; the four sums
+                              are added through LDS in ascending source order (a third level of the sum, like the reference's 16
+                              partial sums + adder tree, S/fxyz.vhd:129-145, S/final_adder.vhd:88-104).  Same workgroup count and
+                              walk per wave from a quarter of the global partial sums.  1: a workgroup owns 256 x IBLOCK bodies,
+                              every wave walks the whole segment (round 2's layout; the LDS / READLANE / FPGA16 kernels always).
+                              -1 (default): 4 wherever the kernel has it (SMEM and ISA deliveries, one body per lane), except with
+                              NBODY_SUM_SEQ in fp32, which means ONE sequential sum per segment. */
   NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: which generated form of the hand-scheduled loop runs (tools/gen_force_loop.py).
-                              1 = the product loop (default).  Kept so that the measurements in profiles/r02_loop_diagnostics.md
-                              can be repeated: 0 = the same instructions placed one 4-byte phase off (-27 %); 2 = staggered
-                              s_load_dwordx8 delivery (-3 %); 9, 10, 11, 13 = 32-bit encodings of the subtractions / of
-                              everything (-4 .. -31 %); 12 = round 1's loop (eps in an SGPR, -0.4 .. -1 %); 16 = v_subrev (-0.8 %);
-                              17 = dx, dy in one v_pk_add_f32 (-9.5 %); 18 = eps from a VGPR instead of the
-                              v_fmaak_f32 literal (-0.3 %) — all of these
-                              bit-identical to the product loop.  3..8, 14, 15 = TIMING-ONLY diagnostic loops WITH WRONG
-                              RESULTS (no transcendental, no scalar loads, VGPR-sourced operands, an LDS read per source, ...)
-                              that price one part of the loop inside the real kernel; never use them for results.
-                              fp64: 1 = the product loop (VALU instructions at 0 mod 8 bytes), 0 = one 4-byte phase off
-                              (-1.2 %), 2 = eps and 3/8 from VGPR pairs (-0.9 %); other values run form 1. */
+                              1 = the product loop (default); 0 = the same instructions placed one 4-byte phase off (-27 %, kept
+                              so that the placement effect can be re-measured).  fp64: 1 = the product loop (VALU instructions at
+                              0 mod 8 bytes), 0 = one phase off (-1.2 %), 2 = eps and 3/8 from VGPR pairs (-0.9 %).
+                              Every other value (fp32 2..18: experiment encodings of the same operations, and TIMING-ONLY forms
+                              WITH WRONG RESULTS that price one part of the loop, profiles/r02_loop_diagnostics.md) exists only in
+                              the diagnostic build `make diag` (libnbody_hip_diag.so, -DNBODY_DIAG_LOOPS); this library answers
+                              NBODY_ERR_UNSUPPORTED. */
 };
 enum { NBODY_VARIANT_AUTO = 0,     /* ISA for the timed arithmetic (fp32, FMA3, blocked or sequential sum), else SMEM */
        NBODY_VARIANT_SMEM = 1,     /* wave-uniform scalar loads (s_load_dwordx16) into SGPRs: no LDS, no VALU cost */
@@ -103,7 +106,10 @@ enum { NBODY_SUM_SEQ = 0,          /* one accumulator per segment, sources ascen
                                       fp64 contexts always sum sequentially. */ };
 enum { NBODY_COMM_RING = 0,        /* P-1 ncclSend/ncclRecv ring steps, one event per arriving slice */
        NBODY_COMM_ALLGATHER = 1,   /* one in-place ncclAllGather (needs N divisible by the rank count, else ring) */
-       NBODY_COMM_AUTO = 2,        /* default: RING (the north_star's form) */
+       NBODY_COMM_AUTO = 2,        /* default: ONE RCCL kernel per step, enqueued ahead of the force launch — ALLGATHER (RCCL's own ring over
+                                      xGMI) when N is divisible by the rank count, DIRECT otherwise (profiles/r03_comm_under_load.md:
+                                      a transfer kernel enqueued beside a force launch that fills every CU waits for wave slots, and
+                                      P-1 dependent ring groups wait P-1 times) */
        NBODY_COMM_DIRECT = 3       /* one group of P-1 sends of the own slice and P-1 receives: one hop over all xGMI links */ };
 
 /* ---- info keys (nbody_get_info) ---- */
@@ -111,7 +117,12 @@ enum { NBODY_INFO_N = 1, NBODY_INFO_N_LOCAL, NBODY_INFO_FIRST_BODY, NBODY_INFO_R
        NBODY_INFO_VARIANT, NBODY_INFO_IBLOCK, NBODY_INFO_JSUB, NBODY_INFO_NSEG, NBODY_INFO_DEVICE,
        NBODY_INFO_CU_COUNT, NBODY_INFO_CLOCK_KHZ, NBODY_INFO_FP64, NBODY_INFO_TILE, NBODY_INFO_STEPS_DONE,
        NBODY_INFO_SUM_ORDER, NBODY_INFO_SUM_BLOCK, NBODY_INFO_LAUNCHES_PER_STEP /* kernel launches one nbody_step() step takes */,
-       NBODY_INFO_HAS_COMM /* 1: an RCCL communicator exists */ };
+       NBODY_INFO_HAS_COMM /* 1: an RCCL communicator exists */,
+       NBODY_INFO_WSPLIT /* resolved NBODY_OPT_WSPLIT: 1 or 4 */, NBODY_INFO_ISA_PHASE, NBODY_INFO_LONG_BUFFERS /* option value, -1 = auto */,
+       NBODY_INFO_XCD_MAP /* option value, -1 = auto */, NBODY_INFO_FUSE_COMBINE /* resolved: 1 = in-launch combine */,
+       NBODY_INFO_COMM_FORM /* resolved NBODY_COMM_* of a multi-rank context, -1 with one rank */,
+       NBODY_INFO_COMM_PRIORITY /* HIP priority of the transfer stream (0 = default priority) */,
+       NBODY_INFO_DIAG_BUILD /* 1: this is libnbody_hip_diag.so (timing-only loop forms present) */ };
 
 /* ---- lifetime ----
  * Replaces: power-up of the PL design + the ps_pl RAM allocation (S/top_level.vhd:100-117, 148-163). */
@@ -128,6 +139,21 @@ int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void 
  * all-gather of a patterned array in the configured NBODY_OPT_COMM form and one grouped ncclSend/ncclRecv ring step,
  * every received word checked.  Collective: every rank calls it.  *bytes_moved (may be NULL) = bytes this rank received. */
 int nbody_comm_selftest(long long *bytes_moved);
+/* The transfer plans of `vranks` VIRTUAL ranks (2..16; a job of that many ranks over this context's N bodies, ragged slices
+ * included) in form NBODY_COMM_RING or NBODY_COMM_DIRECT, executed through real ncclSend/ncclRecv on the ONE-rank
+ * communicator of nbody_init_rank(..., nranks = 1, uid): each virtual rank has its own array holding its own slice, every
+ * receive is issued with the send its peer's plan pairs with it, and afterwards every array must hold all N words.  How a
+ * one-GPU box runs the P > 1 offsets, byte counts and pairing of the data path. */
+int nbody_comm_selftest_virtual(int vranks, int form, long long *bytes_moved);
+/* The transfer plan nbody_step() executes for rank `rank` of `nranks` over n bodies (form NBODY_COMM_RING or _DIRECT):
+ * 7 values per send/receive pair {group, send_peer, send_first_word, send_words, recv_peer, recv_first_word, recv_words},
+ * pairs of one group go into one ncclGroupStart/End.  Pure host arithmetic: needs no GPU and no context.  ops may be NULL
+ * (count only); *n_ops = nranks - 1. */
+int nbody_comm_plan(int form, int rank, int nranks, int n, long long *ops, int max_ops, int *n_ops);
+/* One RCCL ring step (grouped ncclSend to rank+1 / ncclRecv from rank-1) of `bytes` on the transfer stream, timed from
+ * enqueue to completion with HIP events: when = 0 alone, 1 enqueued just before a full force pass, 2 just after it (the
+ * force launch occupies every CU).  *force_ms = duration of that force pass (0 for when = 0).  Needs a communicator. */
+int nbody_comm_probe(long long bytes, int when, double *comm_ms, double *force_ms);
 void nbody_shutdown(void);
 
 int nbody_set_option(int key, int value);
@@ -166,8 +192,9 @@ int nbody_sync(void);
  * (S/top_level.vhd:206-208), force_words = N x {Fx, Fy, Fz, 0} (S/compute_store.vhd:213, 242). */
 int nbody_forces(const float *pos_words, float *force_words, int n);
 int nbody_forces_d(const double *pos_words, double *force_words, int n);
-/* Forces on `n_rows` bodies starting at `first_row`, from the state already on the device
- * (row-sampled parity checks at N = 1M). */
+/* Forces on `n_rows` bodies starting at `first_row`, from the state already on the device (row-sampled parity checks at
+ * N = 1M).  first_row: in an nbody_init context (one process, one or several devices) the GLOBAL body index — the range may
+ * span devices; in an nbody_init_rank context the row within this rank's own slice. */
 int nbody_forces_rows(int first_row, int n_rows, float *force_words);
 int nbody_forces_rows_d(int first_row, int n_rows, double *force_words);
 
@@ -187,6 +214,10 @@ int nbody_set_host_gather(nbody_host_gather_fn fn, void *user);
 
 /* Sum of HIP-event durations of the force kernels since the last reset (NBODY_OPT_TIMING = 1). */
 int nbody_kernel_time(double *ms_total, long long *launches, int reset);
+
+/* Exposed communication: how long the compute stream sat waiting for arriving slices since the last reset (HIP events
+ * around every such wait, NBODY_OPT_TIMING = 1).  0 when everything arrived while the own-slice kernel was running. */
+int nbody_comm_time(double *wait_ms_total, long long *waits, int reset);
 
 /* Device pointers of the resident state (for zero-copy interop with a framework that owns a view):
  * which = 0 current positions (full N), 1 velocities (own slice), 2 last forces (own slice). */

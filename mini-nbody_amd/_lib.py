@@ -7,18 +7,20 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnbody_hip.so")
+# NBODY_LIB selects another build of the same C-ABI (the diagnostic library of `make diag`); there is still no fallback
+LIB_PATH = os.environ.get("NBODY_LIB") or os.path.join(HERE, "libnbody_hip.so")
 
 # mirrors of the enums in include/nbody.h
 (OPT_VARIANT, OPT_IBLOCK, OPT_JSUB, OPT_JSLICES, OPT_ARITH, OPT_SUM_ORDER, OPT_TIMING, OPT_COMM, OPT_OVERLAP, OPT_ISA_PHASE,
- OPT_WAVES_PER_SIMD, OPT_GRAPH, OPT_SUM_BLOCK, OPT_FUSE_COMBINE, OPT_ISA_LONG_BUFFERS, OPT_XCD_MAP) = range(1, 17)
+ OPT_WAVES_PER_SIMD, OPT_GRAPH, OPT_SUM_BLOCK, OPT_FUSE_COMBINE, OPT_ISA_LONG_BUFFERS, OPT_XCD_MAP, OPT_WSPLIT) = range(1, 18)
 VARIANT_AUTO, VARIANT_SMEM, VARIANT_LDS, VARIANT_READLANE, VARIANT_ISA = range(5)
 ARITH_FMA3, ARITH_REFERENCE, ARITH_STRICT, ARITH_REFERENCE_STRICT = 0, 1, 2, 3
 SUM_SEQ, SUM_FPGA16, SUM_BLOCKED = 0, 1, 2
 COMM_RING, COMM_ALLGATHER, COMM_AUTO, COMM_DIRECT = 0, 1, 2, 3
 (INFO_N, INFO_N_LOCAL, INFO_FIRST_BODY, INFO_RANK, INFO_NRANKS, INFO_VARIANT, INFO_IBLOCK, INFO_JSUB, INFO_NSEG,
  INFO_DEVICE, INFO_CU_COUNT, INFO_CLOCK_KHZ, INFO_FP64, INFO_TILE, INFO_STEPS_DONE, INFO_SUM_ORDER, INFO_SUM_BLOCK,
- INFO_LAUNCHES_PER_STEP, INFO_HAS_COMM) = range(1, 20)
+ INFO_LAUNCHES_PER_STEP, INFO_HAS_COMM, INFO_WSPLIT, INFO_ISA_PHASE, INFO_LONG_BUFFERS, INFO_XCD_MAP, INFO_FUSE_COMBINE,
+ INFO_COMM_FORM, INFO_COMM_PRIORITY, INFO_DIAG_BUILD) = range(1, 28)
 
 ERR_NOT_INIT, ERR_ARG, ERR_NO_DEVICE, ERR_RCCL_LOAD, ERR_STATE, ERR_UNSUPPORTED = 1001, 1002, 1003, 1004, 1005, 1006
 
@@ -29,6 +31,7 @@ SYMBOLS = [
     "integrate", "bodyForce_d", "integrate_d", "nbody_step", "nbody_step_d", "nbody_sync", "nbody_forces",
     "nbody_forces_d", "nbody_forces_rows", "nbody_mailbox_run", "nbody_kernel_time", "nbody_device_ptr",
     "nbody_set_host_gather", "nbody_download_slice", "nbody_comm_selftest", "nbody_forces_rows_d",
+    "nbody_comm_selftest_virtual", "nbody_comm_plan", "nbody_comm_probe", "nbody_comm_time",
 ]
 
 
@@ -70,6 +73,10 @@ def load():
         "integrate_d": [dp, dp, d, i], "nbody_step": [f, i], "nbody_step_d": [d, i], "nbody_sync": [],
         "nbody_forces": [fp, fp, i], "nbody_forces_d": [dp, dp, i], "nbody_forces_rows": [i, i, fp], "nbody_forces_rows_d": [i, i, dp],
         "nbody_comm_selftest": [C.POINTER(C.c_longlong)],
+        "nbody_comm_selftest_virtual": [i, i, C.POINTER(C.c_longlong)],
+        "nbody_comm_plan": [i, i, i, i, C.POINTER(C.c_longlong), i, C.POINTER(i)],
+        "nbody_comm_probe": [C.c_longlong, i, C.POINTER(d), C.POINTER(d)],
+        "nbody_comm_time": [C.POINTER(d), C.POINTER(C.c_longlong), i],
         "nbody_mailbox_run": [vp, vp, i], "nbody_kernel_time": [C.POINTER(d), C.POINTER(C.c_longlong), i],
         "nbody_device_ptr": [i, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "nbody_set_host_gather": [HOST_GATHER_FN, vp], "nbody_download_slice": [vp, vp],

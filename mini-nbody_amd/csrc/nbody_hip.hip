@@ -76,6 +76,14 @@ int rccl_load() {
   return NBODY_OK;
 }
 
+// a ring of HIP event pairs whose durations are summed lazily (no host sync while a step is being enqueued)
+struct EventTimer {
+  hipEvent_t t0[kTimerRing] = {}, t1[kTimerRing] = {};
+  int head = 0, count = 0;
+  double ms = 0.0;
+  long long n = 0;
+};
+
 struct Local {
   int device = 0, rank = 0;
   int first = 0, n_local = 0;          // owned bodies
@@ -92,17 +100,15 @@ struct Local {
   hipEvent_t ev_own_ready = nullptr;   // the rank's slice of pos[cur] is written
   hipEvent_t ev_gather[kMaxRanks] = {};
   ncclComm_t comm_h = nullptr;
-  // force-kernel timing
-  hipEvent_t t0[kTimerRing] = {}, t1[kTimerRing] = {};
-  int t_head = 0, t_count = 0;
-  double t_ms = 0.0;
-  long long t_launches = 0;
+  EventTimer kern;   // force kernels (NBODY_OPT_TIMING)
+  EventTimer wait;   // how long the compute stream sat waiting for arriving slices: exposed communication
 };
 
 struct Options {
   int variant = NBODY_VARIANT_AUTO, iblock = 0, jsub = 0, jslices = 0;
   int arith = NBODY_ARITH_FMA3, sum_order = NBODY_SUM_BLOCKED, sum_block = 1024, fuse = -1;
   int timing = 0, comm = NBODY_COMM_AUTO, overlap = 1, isa_phase = 1, waves_per_simd = 0, graph = 1, long_buffers = -1, xcd_map = -1;
+  int wsplit = -1;
 };
 
 // what happens to the force of a row once all its segments are summed
@@ -127,7 +133,10 @@ struct Global {
   Options opt;
   // resolved launch configuration
   int variant = NBODY_VARIANT_SMEM, R = 4, sub = 1, nslices = 1, nseg = 1, fuse = 1;
+  int wsplit = 1;                 // 4: a workgroup owns 64 rows, its four waves walk a quarter of the segment each (ForceArgs::wsplit)
+  bool tickets_dirty = false;     // a step failed after some of its launches: the arrival counters may be non-zero
   int cu_count = 0, clock_khz = 0;
+  int comm_priority = 0;          // HIP priority of the transfer streams (0 = default)
   long long steps_done = 0;
 };
 Global g;
@@ -135,7 +144,10 @@ Global g;
 inline size_t word_bytes() { return g.fp64 ? 32 : 16; }
 inline char* word_ptr(void* base, size_t word) { return (char*)base + word * word_bytes(); }
 
-int blocks_for(int rows, int R) { return (rows + kBlock * R - 1) / (kBlock * R); }
+inline int rows_per_wg(int R, int wsplit) { return wsplit > 1 ? 64 : kBlock * R; }
+int blocks_for(int rows, int R, int wsplit) { const int w = rows_per_wg(R, wsplit); return (rows + w - 1) / w; }
+// words between two segments' partial sums: the launch's rows rounded up to 64 (ForceArgs::part_stride)
+inline size_t part_stride(int rows) { return ((size_t)rows + 63) / 64 * 64; }
 
 // Choose R (bodies per lane) and sub (pieces per source slice).  Measured at N = 1M on MI355X (profiles/r01_sweep.txt):
 // one body per lane (16 waves per SIMD worth of work, 8 resident) beats 2/4/8 bodies per lane — hipcc software-pipelines
@@ -156,6 +168,14 @@ void resolve_config() {
   if (g.fp64 && R > 4) R = 4;
   if (g.opt.sum_order == NBODY_SUM_FPGA16 && !g.fp64) R = 1;
   g.R = R;
+  // The wave split (ForceArgs::wsplit) exists in the scalar-delivery kernels with one body per lane; the LDS and READLANE
+  // deliveries stage sources for the whole workgroup and the FPGA order is a study of the reference's own tree.
+  const bool can_split = (g.variant == NBODY_VARIANT_ISA || g.variant == NBODY_VARIANT_SMEM) && R == 1 &&
+                         (g.fp64 || g.opt.sum_order != NBODY_SUM_FPGA16);
+  // automatic: wherever it exists, except for NBODY_SUM_SEQ in fp32, whose meaning is ONE sequential sum per segment (what a CPU
+  // nbody.c does); fp64 contexts, which always sum sequentially and have 29 bits to spare, take the split
+  const bool auto_split = g.fp64 || g.opt.sum_order != NBODY_SUM_SEQ;
+  g.wsplit = (can_split && (g.opt.wsplit == 4 || (g.opt.wsplit < 0 && auto_split))) ? 4 : 1;
   // Small launches and large ones want different things (profiles/r02_small_n.md, one process, wall clock per step):
   //   large (even 64 segments give >= 16 workgroups per CU; N >= 16384 on one GPU): many short segments for load
   //     balance over the 256 CUs — 128 workgroups per CU in the launch, up to 64 segments of >= 128 sources (N = 65536:
@@ -166,7 +186,7 @@ void resolve_config() {
   //     64: 19.4; N = 8192: 16 segments 27.2, 64: 31.8) and the sums added by a second small kernel — in one launch the
   //     hand-off is exposed (N = 4096: 22.7 us, N = 8192: 36.4).
   const int cus = g.cu_count > 0 ? g.cu_count : 256;
-  const int blocks = blocks_for(n_local, R);
+  const int blocks = blocks_for(n_local, R, 1);   // in workgroups of 256*R rows: `sub` below counts pieces of a slice as round 2 did
   const bool small = (long long)blocks * 64 < 16LL * cus;
   int sub = g.opt.jsub;
   if (sub == 0) {
@@ -184,19 +204,44 @@ void resolve_config() {
     const int mem_sub = (int)std::max(1LL, std::max(8LL, words_cap) / g.nslices);
     sub = std::min(sub, std::max(mem_sub, (target_blocks + blocks - 1) / blocks));
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
+    if (g.wsplit > 1) {
+      // With the wave split a workgroup has a quarter of the rows and its waves a quarter of the segment each: the same
+      // number of workgroups and the same walk per wave come from a QUARTER of the global segments (partial sums, tickets,
+      // last-arriver rounds) — but not fewer than keep a segment inside one XCD's L2 share (2 MiB: N = 1M fp32 stays at 8,
+      // one per XCD, each fetched once; four waves walking four quarters of an 8 MiB segment would stream it per resident set)
+      const long long slice_bytes = (long long)slice_len * (long long)word_bytes();
+      const int l2_sub = (int)((slice_bytes + (2LL << 20) - 1) / (2LL << 20));
+      sub = std::max((sub + g.wsplit - 1) / g.wsplit, std::min(sub, l2_sub));
+    }
   }
   g.sub = sub;
   g.nseg = g.nslices * g.sub;
   g.fuse = g.opt.fuse < 0 ? (small ? 0 : 1) : g.opt.fuse;
 }
 
-// arrival counters: one per wave (4) of every block of 256 rows, padded to a multiple of 16 bytes
-size_t ticket_words(const Local& L) { return ((size_t)blocks_for(L.n_local, 1) * 4 + 63) / 64 * 64; }
+// arrival counters: one per 64 rows (a wave's rows), with slack for the row blocks of 256*R rows whose waves count in
+// strides of 4*R, padded to a multiple of 256 bytes
+size_t ticket_words(const Local& L) { return ((size_t)(L.n_local + 63) / 64 + 32 + 63) / 64 * 64; }
 
 int alloc_local(Local& L) {
   HIPC(hipSetDevice(L.device));
   HIPC(hipStreamCreateWithFlags(&L.compute, hipStreamNonBlocking));
-  HIPC(hipStreamCreateWithFlags(&L.comm, hipStreamNonBlocking));
+  {
+    // The transfers' kernels (RCCL) and copies are small and the force launch beside them fills every wave slot of every
+    // CU: the second stream gets the highest priority the device offers, so that its work is dispatched ahead of the
+    // force kernel's remaining workgroups (profiles/r03_comm_under_load.md).  NBODY_COMM_PRIORITY=0 turns it off (A/B).
+    int least = 0, greatest = 0;
+    const char* pe = getenv("NBODY_COMM_PRIORITY");
+    const bool want = !(pe && *pe && atoi(pe) == 0);
+    if (want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+      HIPC(hipStreamCreateWithPriority(&L.comm, hipStreamNonBlocking, greatest));
+      g.comm_priority = greatest;
+    } else {
+      (void)hipGetLastError();
+      HIPC(hipStreamCreateWithFlags(&L.comm, hipStreamNonBlocking));
+      g.comm_priority = 0;
+    }
+  }
   const size_t wb = word_bytes();
   const size_t pad = 64;   // words of slack after the arrays (never read by the kernels; keeps SMEM groups in-bounds by construction anyway)
   for (int b = 0; b < 2; ++b) { HIPC(hipMalloc(&L.pos[b], (g.n + pad) * wb)); HIPC(hipMemset(L.pos[b], 0, (g.n + pad) * wb)); }
@@ -209,12 +254,13 @@ int alloc_local(Local& L) {
   HIPC(hipMemset(L.force, 0, (L.n_local + pad) * wb));
   HIPC(hipEventCreateWithFlags(&L.ev_own_ready, hipEventDisableTiming));
   for (int s = 0; s < g.nranks && s < kMaxRanks; ++s) HIPC(hipEventCreateWithFlags(&L.ev_gather[s], hipEventDisableTiming));
-  for (int k = 0; k < kTimerRing; ++k) { HIPC(hipEventCreate(&L.t0[k])); HIPC(hipEventCreate(&L.t1[k])); }
+  for (EventTimer* T : {&L.kern, &L.wait})
+    for (int k = 0; k < kTimerRing; ++k) { HIPC(hipEventCreate(&T->t0[k])); HIPC(hipEventCreate(&T->t1[k])); }
   return NBODY_OK;
 }
 
 int ensure_partial(Local& L) {
-  const size_t need = (size_t)g.nseg * (size_t)L.n_local;
+  const size_t need = (size_t)g.nseg * part_stride(L.n_local);
   if (L.partial && need <= L.partial_words) return NBODY_OK;
   HIPC(hipSetDevice(L.device));
   if (L.partial) { HIPC(hipFree(L.partial)); L.partial = nullptr; L.partial_words = 0; }
@@ -229,9 +275,13 @@ void drop_step_graph() {
 }
 
 int reconfigure() {
-  const int o_variant = g.variant, o_R = g.R, o_sub = g.sub, o_nsl = g.nslices, o_fuse = g.fuse;
+  const int o_variant = g.variant, o_R = g.R, o_sub = g.sub, o_nsl = g.nslices, o_fuse = g.fuse, o_ws = g.wsplit;
   resolve_config();
-  const bool changed = o_variant != g.variant || o_R != g.R || o_sub != g.sub || o_nsl != g.nslices || o_fuse != g.fuse;
+  // (a step that failed after some of its launches leaves arrival counters at a partial count: the next step would combine
+  //  early.  Every failing path sets tickets_dirty; the counters are re-zeroed here, before anything else is launched.)
+  const bool changed = o_variant != g.variant || o_R != g.R || o_sub != g.sub || o_nsl != g.nslices || o_fuse != g.fuse || o_ws != g.wsplit ||
+                       g.tickets_dirty;
+  g.tickets_dirty = false;
   if (changed) drop_step_graph();
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
@@ -246,48 +296,56 @@ int reconfigure() {
   return NBODY_OK;
 }
 
-// ---- force-kernel timing ring ----
-int timer_drain(Local& L, int keep) {
-  while (L.t_count > keep) {
-    int idx = (L.t_head - L.t_count + 2 * kTimerRing) % kTimerRing;
-    HIPC(hipEventSynchronize(L.t1[idx]));
+// ---- event timers ----
+int timer_drain(EventTimer& T, int keep) {
+  while (T.count > keep) {
+    int idx = (T.head - T.count + 2 * kTimerRing) % kTimerRing;
+    HIPC(hipEventSynchronize(T.t1[idx]));
     float ms = 0.f;
-    HIPC(hipEventElapsedTime(&ms, L.t0[idx], L.t1[idx]));
-    L.t_ms += ms;
-    L.t_launches += 1;
-    L.t_count--;
+    HIPC(hipEventElapsedTime(&ms, T.t0[idx], T.t1[idx]));
+    T.ms += ms;
+    T.n += 1;
+    T.count--;
   }
+  return NBODY_OK;
+}
+// begin/end of one timed span on `stream`; begin returns the slot (or -1 when timing is off)
+int timer_begin(EventTimer& T, hipStream_t stream, int* slot) {
+  *slot = -1;
+  if (!g.opt.timing) return NBODY_OK;
+  if (T.count == kTimerRing) NBC(timer_drain(T, kTimerRing / 2));
+  *slot = T.head;
+  HIPC(hipEventRecord(T.t0[*slot], stream));
+  return NBODY_OK;
+}
+int timer_end(EventTimer& T, hipStream_t stream, int slot) {
+  if (slot < 0) return NBODY_OK;
+  HIPC(hipEventRecord(T.t1[slot], stream));
+  T.head = (T.head + 1) % kTimerRing;
+  T.count++;
   return NBODY_OK;
 }
 
 template <typename K>
 int launch_timed(Local& L, K kernel, dim3 grid, const ForceArgs& a) {
-  int idx = -1;
-  if (g.opt.timing) {
-    if (L.t_count == kTimerRing) NBC(timer_drain(L, kTimerRing / 2));
-    idx = L.t_head;
-    HIPC(hipEventRecord(L.t0[idx], L.compute));
-  }
+  int slot;
+  NBC(timer_begin(L.kern, L.compute, &slot));
   // optional occupancy cap: k workgroups (= k waves per SIMD) per CU by giving each 160 KiB / k of dynamic LDS
   size_t dyn_lds = 0;
   if (g.opt.waves_per_simd > 0 && g.opt.waves_per_simd < 8) {
-    dyn_lds = (size_t)(160 * 1024) / (size_t)g.opt.waves_per_simd - 512 - (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0);
+    const size_t static_lds = (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0) + (a.wsplit > 1 ? 3 * 64 * word_bytes() : 0);
+    dyn_lds = (size_t)(160 * 1024) / (size_t)g.opt.waves_per_simd - 512 - static_lds;
     if (dyn_lds > 64 * 1024) HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(kernel, grid, dim3(kBlock), dyn_lds, L.compute, a);
   HIPC(hipGetLastError());
-  if (idx >= 0) {
-    HIPC(hipEventRecord(L.t1[idx], L.compute));
-    L.t_head = (L.t_head + 1) % kTimerRing;
-    L.t_count++;
-  }
-  return NBODY_OK;
+  return timer_end(L.kern, L.compute, slot);
 }
 
 template <int R, int ARITH>
 int launch_f32_RA(Local& L, dim3 grid, const ForceArgs& a) {
   if constexpr (R == 8) {   // 8 bodies per lane only exists for the SMEM variant
-    return launch_timed(L, force_smem_f32<R, ARITH>, grid, a);
+    return launch_timed(L, force_smem_f32<R, ARITH, 1>, grid, a);
   } else {
     switch (g.variant) {
       case NBODY_VARIANT_LDS:
@@ -297,7 +355,8 @@ int launch_f32_RA(Local& L, dim3 grid, const ForceArgs& a) {
       case NBODY_VARIANT_READLANE:
         return launch_timed(L, force_readlane_f32<R, ARITH>, grid, a);
       default:
-        return launch_timed(L, force_smem_f32<R, ARITH>, grid, a);
+        if constexpr (R == 1) { if (a.wsplit > 1) return launch_timed(L, force_smem_f32<1, ARITH, 4>, grid, a); }
+        return launch_timed(L, force_smem_f32<R, ARITH, 1>, grid, a);
     }
   }
 }
@@ -311,6 +370,19 @@ int launch_f32_R(Local& L, dim3 grid, const ForceArgs& a) {
     default: return launch_f32_RA<R, 0>(L, grid, a);
   }
 }
+
+// the hand-scheduled fp32 loop in form PH (NBODY_OPT_ISA_PHASE), with or without the wave split
+template <int PH>
+int launch_isa_f32(Local& L, dim3 grid, const ForceArgs& a) {
+  return a.wsplit > 1 ? launch_timed(L, force_isa_f32<PH, 4>, grid, a) : launch_timed(L, force_isa_f32<PH, 1>, grid, a);
+}
+template <int PH>
+int launch_isa_f64(Local& L, dim3 grid, const ForceArgs& a) {
+  return a.wsplit > 1 ? launch_timed(L, force_isa_f64<PH, 4>, grid, a) : launch_timed(L, force_isa_f64<PH, 1>, grid, a);
+}
+
+// loop forms that exist in the diagnostic build only (make diag): experiment encodings and timing-only forms
+inline bool isa_phase_is_diag(int ph) { return ph >= 2; }
 
 // how a launch finishes its rows: directly (one segment), by the last-arriving workgroup, or by combine_kernel
 inline int finish_mode() { return g.nseg == 1 ? kFinishDirect : (g.fuse ? kFinishLast : kFinishStore); }
@@ -330,6 +402,8 @@ void fill_args(Local& L, ForceArgs& a, int row0, int row_count, const Finish& fi
   a.do_kick = fin.kick; a.do_drift = fin.drift;
   a.sum_block = (!g.fp64 && g.opt.sum_order == NBODY_SUM_BLOCKED) ? g.opt.sum_block : 0;
   a.fpga16 = g.opt.sum_order == NBODY_SUM_FPGA16;
+  a.wsplit = g.wsplit;
+  a.part_stride = (int)part_stride(row_count);
   a.dt = dt; a.dt64 = dt64;
 }
 
@@ -343,28 +417,31 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   fill_args(L, a, row0, row_count, fin, dt, dt64);
   a.slice_start = slice_start;
   const int R = g.R;
-  dim3 grid(blocks_for(row_count, R), nsl * g.sub, 1);
+  dim3 grid(blocks_for(row_count, R, g.wsplit), nsl * g.sub, 1);
   // few workgroups per CU = few waves per SIMD and short segments: the scalar loads are no longer hidden by other waves
   const int cus = g.cu_count > 0 ? g.cu_count : 256;
   // (measured at N = 16384, 16 workgroups per CU: +4 % with the long buffers; N = 65536, 64 per CU: -2 %)
-  // XCD-aware placement of segments (block_segment): needs a multiple of 8 segment rows in the launch.  Automatic: for
-  // launches of >= 4096 row blocks (N = 1M on one GPU: sources fetched once per XCD, 477 MB of memory-side traffic per step
-  // instead of 788, time level); with fewer row blocks it measured slower (N = 262144: -2 %, N = 16384: -18 %)
-  a.xcd_map = ((g.opt.xcd_map > 0 || (g.opt.xcd_map < 0 && grid.x >= 4096)) && grid.y % 8 == 0) ? 1 : 0;
+  // XCD-aware placement of segments (block_segment): needs a multiple of 8 segment rows in the launch, or 1/2/4 of them and a
+  // row-block count the 8 / rows XCDs of a segment can deal evenly.  Automatic: for launches whose source set is larger than one
+  // XCD's L2 share (N = 1M on one GPU: sources fetched once per XCD, 477 MB of memory-side traffic per step
+  // instead of 788, time level); for smaller ones it measured slower (N = 262144: -2 %, N = 16384: -18 %: the last arrivers
+  // of every row block then sit on one XCD, profiles/r02_small_n.md)
+  const bool xcd_ok = grid.y % 8 == 0 || ((grid.y == 1 || grid.y == 2 || grid.y == 4) && grid.x % (8 / grid.y) == 0);
+  const bool xcd_auto = (long long)blocks_for(row_count, 1, 1) >= 4096;
+  a.xcd_map = ((g.opt.xcd_map > 0 || (g.opt.xcd_map < 0 && xcd_auto)) && xcd_ok) ? 1 : 0;
   a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y < 32LL * cus ? 1 : 0) : g.opt.long_buffers;
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
-    if (g.opt.isa_phase == 2) return launch_timed(L, force_isa_f64<2>, grid, a);
-    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f64<0>, grid, a) : launch_timed(L, force_isa_f64<1>, grid, a);
+    if (g.opt.isa_phase == 2) return launch_isa_f64<2>(L, grid, a);
+    return g.opt.isa_phase == 0 ? launch_isa_f64<0>(L, grid, a) : launch_isa_f64<1>(L, grid, a);
   }
   if (g.fp64) {
     switch (R) {
-      case 1: return launch_timed(L, force_smem_f64<1>, grid, a);
-      case 2: return launch_timed(L, force_smem_f64<2>, grid, a);
-      default: return launch_timed(L, force_smem_f64<4>, grid, a);
+      case 1: return a.wsplit > 1 ? launch_timed(L, force_smem_f64<1, 4>, grid, a) : launch_timed(L, force_smem_f64<1, 1>, grid, a);
+      case 2: return launch_timed(L, force_smem_f64<2, 1>, grid, a);
+      default: return launch_timed(L, force_smem_f64<4, 1>, grid, a);
     }
   }
   if (a.fpga16) {
-    grid.x = blocks_for(row_count, 1);
     switch (g.opt.arith) {
       case NBODY_ARITH_REFERENCE: return launch_timed(L, force_fpga16_f32<1>, grid, a);
       case NBODY_ARITH_STRICT: return launch_timed(L, force_fpga16_f32<2>, grid, a);
@@ -373,28 +450,30 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
     }
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
-    if (a.long_buffers) return launch_timed(L, force_isa_long_f32, grid, a);
+    if (a.long_buffers) return a.wsplit > 1 ? launch_timed(L, force_isa_long_f32<4>, grid, a) : launch_timed(L, force_isa_long_f32<1>, grid, a);
     switch (g.opt.isa_phase) {
-      case 2: return launch_timed(L, force_isa_f32<2>, grid, a);
-      case 3: return launch_timed(L, force_isa_f32<3>, grid, a);   // 3..5: timing-only diagnostics, wrong results
-      case 4: return launch_timed(L, force_isa_f32<4>, grid, a);
-      case 5: return launch_timed(L, force_isa_f32<5>, grid, a);
-      case 6: return launch_timed(L, force_isa_f32<6>, grid, a);
-      case 7: return launch_timed(L, force_isa_f32<7>, grid, a);
-      case 8: return launch_timed(L, force_isa_f32<8>, grid, a);
-      case 9: return launch_timed(L, force_isa_f32<9>, grid, a);    // 9..13: correct loops, other encodings (experiments)
-      case 10: return launch_timed(L, force_isa_f32<10>, grid, a);
-      case 11: return launch_timed(L, force_isa_f32<11>, grid, a);
-      case 12: return launch_timed(L, force_isa_f32<12>, grid, a);
-      case 13: return launch_timed(L, force_isa_f32<13>, grid, a);
-      case 14: return launch_timed(L, force_isa_f32<14>, grid, a);   // 14, 15: timing-only diagnostics, wrong results
-      case 15: return launch_timed(L, force_isa_f32<15>, grid, a);
-      case 16: return launch_timed(L, force_isa_f32<16>, grid, a);   // correct: SGPR operand in src1
-      case 17: return launch_timed(L, force_isa_f32<17>, grid, a);   // correct: dx, dy in one packed subtraction
-      case 18: return launch_timed(L, force_isa_f32<18>, grid, a);   // correct: eps from a VGPR instead of the v_fmaak_f32 literal
-      default: break;
+      case 0: return launch_isa_f32<0>(L, grid, a);
+#ifdef NBODY_DIAG_LOOPS
+      case 2: return launch_isa_f32<2>(L, grid, a);     // 2, 9..13, 16..18: the same operations in other encodings (bit-identical)
+      case 3: return launch_isa_f32<3>(L, grid, a);     // 3..8, 14, 15: TIMING-ONLY forms, WRONG RESULTS
+      case 4: return launch_isa_f32<4>(L, grid, a);
+      case 5: return launch_isa_f32<5>(L, grid, a);
+      case 6: return launch_isa_f32<6>(L, grid, a);
+      case 7: return launch_isa_f32<7>(L, grid, a);
+      case 8: return launch_isa_f32<8>(L, grid, a);
+      case 9: return launch_isa_f32<9>(L, grid, a);
+      case 10: return launch_isa_f32<10>(L, grid, a);
+      case 11: return launch_isa_f32<11>(L, grid, a);
+      case 12: return launch_isa_f32<12>(L, grid, a);
+      case 13: return launch_isa_f32<13>(L, grid, a);
+      case 14: return launch_isa_f32<14>(L, grid, a);
+      case 15: return launch_isa_f32<15>(L, grid, a);
+      case 16: return launch_isa_f32<16>(L, grid, a);
+      case 17: return launch_isa_f32<17>(L, grid, a);
+      case 18: return launch_isa_f32<18>(L, grid, a);
+#endif
+      default: return launch_isa_f32<1>(L, grid, a);
     }
-    return g.opt.isa_phase == 0 ? launch_timed(L, force_isa_f32<0>, grid, a) : launch_timed(L, force_isa_f32<1>, grid, a);
   }
   switch (R) {
     case 1: return launch_f32_R<1>(L, grid, a);
@@ -417,8 +496,6 @@ int launch_combine(Local& L, int row0, int row_count, const Finish& fin, float d
   return NBODY_OK;
 }
 
-inline int ring_slice(int rank, int s) { int q = (rank - s) % g.nranks; return q < 0 ? q + g.nranks : q; }
-
 // Host-staged all-gather of one sharded device array (words [first, first+count) are this rank's): D2H own part,
 // callback (the host framework's all-gather fills the rest of g.host_stage), H2D everything else on the comm stream.
 int host_exchange(Local& L, void* dev_full, int first, int count, bool wait_own_ready) {
@@ -435,9 +512,72 @@ int host_exchange(Local& L, void* dev_full, int first, int count, bool wait_own_
   return NBODY_OK;
 }
 
+inline int ring_slice(int rank, int s) { int q = (rank - s) % g.nranks; return q < 0 ? q + g.nranks : q; }
+
+// ---- the transfer plan of one rank: which words go to / come from whom, in which RCCL group ----
+// A pure function of (form, rank, P, N): rccl_gather() executes it, nbody_comm_plan() exports it so that the CPU tests can
+// check it (every word received exactly once, pair s of rank r matches pair s of its peer, ragged N) without a GPU, and
+// nbody_comm_selftest() runs the plans of P virtual ranks through real ncclSend/ncclRecv on one device.
+//   RING (the north_star's form): P-1 groups; group s forwards the slice that arrived in group s-1 (the rank's own at
+//     s = 1) to rank+1 and receives slice (rank - s) mod P from rank-1; an event after each group releases that slice.
+//   DIRECT: one group of P-1 pairs; pair s sends the own slice to rank+s and receives slice (rank - s) mod P from its owner
+//     — one hop over all 7 xGMI links at once.
+struct CommOp {
+  int group;                       // 1-based RCCL group the pair belongs to
+  int send_peer; long long send_first, send_count;   // words [send_first, send_first + send_count) of the array go to send_peer
+  int recv_peer; long long recv_first, recv_count;   // words [recv_first, ...) are received from recv_peer
+};
+inline int ring_slice_of(int rank, int s, int P) { int q = (rank - s) % P; return q < 0 ? q + P : q; }
+int comm_plan(int form, int rank, int P, int n, std::vector<CommOp>& ops) {
+  ops.clear();
+  if (P < 1 || rank < 0 || rank >= P || n < P) return NBODY_ERR_ARG;
+  if (form != NBODY_COMM_RING && form != NBODY_COMM_DIRECT) return NBODY_ERR_ARG;
+  for (int s = 1; s < P; ++s) {
+    CommOp o;
+    const int qr = ring_slice_of(rank, s, P);      // the slice this pair brings in
+    o.recv_first = slice_first(qr, n, P); o.recv_count = slice_first(qr + 1, n, P) - o.recv_first;
+    if (form == NBODY_COMM_RING) {
+      const int qs = ring_slice_of(rank, s - 1, P);   // forward what arrived last (own slice at s = 1)
+      o.group = s;
+      o.send_peer = (rank + 1) % P; o.recv_peer = (rank + P - 1) % P;
+      o.send_first = slice_first(qs, n, P); o.send_count = slice_first(qs + 1, n, P) - o.send_first;
+    } else {
+      o.group = 1;
+      o.send_peer = (rank + s) % P; o.recv_peer = qr;
+      o.send_first = slice_first(rank, n, P); o.send_count = slice_first(rank + 1, n, P) - o.send_first;
+    }
+    ops.push_back(o);
+  }
+  return NBODY_OK;
+}
+
+// which form NBODY_COMM_AUTO means (profiles/r03_comm_under_load.md): ONE RCCL kernel per step enqueued ahead of the force
+// launch — ncclAllGather (whose algorithm over xGMI is a ring) when the slices are equal, the DIRECT group when they are
+// not — rather than P-1 dependent ring groups, each of which would have to win wave slots from a force kernel that fills
+// every CU.  NBODY_COMM_RING remains the north_star's literal form, one event per arriving slice (NBODY_OPT_OVERLAP 2).
+inline int resolved_comm_form() {
+  const bool even = (g.n % g.nranks) == 0;
+  if (g.opt.comm == NBODY_COMM_AUTO) return even ? NBODY_COMM_ALLGATHER : NBODY_COMM_DIRECT;
+  if (g.opt.comm == NBODY_COMM_ALLGATHER && !even) return NBODY_COMM_RING;
+  return g.opt.comm;
+}
+
+// one RCCL group of a plan: every send and receive of group `grp`, on the comm stream
+int run_plan_group(Local& L, void* dev_full, const std::vector<CommOp>& ops, int grp) {
+  const size_t wb = word_bytes();
+  NCCLC(g_rccl.GroupStart());
+  for (const CommOp& o : ops) {
+    if (o.group != grp) continue;
+    NCCLC(g_rccl.Send(word_ptr(dev_full, (size_t)o.send_first), (size_t)o.send_count * wb, ncclChar, o.send_peer, L.comm_h, L.comm));
+    NCCLC(g_rccl.Recv(word_ptr(dev_full, (size_t)o.recv_first), (size_t)o.recv_count * wb, ncclChar, o.recv_peer, L.comm_h, L.comm));
+  }
+  NCCLC(g_rccl.GroupEnd());
+  return NBODY_OK;
+}
+
 // One ring step on the comm stream: send `send_bytes` at `send_ptr` to the next rank, receive `recv_bytes` at `recv_ptr`
 // from the previous one, as one RCCL group (so neither side blocks the other).  With one rank next = prev = self and the
-// pair is a device-local copy through RCCL (what nbody_comm_selftest runs on a one-GPU box).
+// pair is a device-local copy through RCCL (nbody_comm_selftest, nbody_comm_probe on a one-GPU box).
 int ring_step(Local& L, const void* send_ptr, size_t send_bytes, void* recv_ptr, size_t recv_bytes) {
   const int P = g.nranks;
   const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
@@ -448,42 +588,27 @@ int ring_step(Local& L, const void* send_ptr, size_t send_bytes, void* recv_ptr,
   return NBODY_OK;
 }
 
-// RCCL all-gather of one sharded device array in place on the comm stream (multi-process).  Default (NBODY_COMM_AUTO,
-// NBODY_COMM_RING): the north_star's ring — P-1 steps, step s forwards the slice that arrived at step s-1 (the rank's
-// own at s = 1) and receives slice (rank - s) mod P; ev[s], if given, is recorded as soon as that slice has landed, so
-// the force kernel over it can start while the next one travels.  NBODY_COMM_ALLGATHER: one in-place ncclAllGather
-// (equal slices only; all events after the collective).
+// RCCL all-gather of one sharded device array in place on the comm stream (multi-process), in the resolved form:
+// one in-place ncclAllGather (equal slices), or the plan above group by group.  ev[s] (s = 1..P-1), if given, is
+// recorded as soon as ring slice s has landed (RING: after its group, so the force kernel over it can start while the
+// next one travels; the single-kernel forms: all after the collective).
 int rccl_gather(Local& L, void* dev_full, hipEvent_t* ev) {
   const int P = g.nranks;
   const size_t wb = word_bytes();
-  const bool even = (g.n % P) == 0;
-  if (even && g.opt.comm == NBODY_COMM_ALLGATHER) {
+  const int form = resolved_comm_form();
+  if (form == NBODY_COMM_ALLGATHER) {
     NCCLC(g_rccl.AllGather(word_ptr(dev_full, L.first), dev_full, (size_t)L.n_local * wb, ncclChar, L.comm_h, L.comm));
     if (ev) for (int s = 1; s < P; ++s) HIPC(hipEventRecord(ev[s], L.comm));
     return NBODY_OK;
   }
-  if (g.opt.comm == NBODY_COMM_DIRECT) {
-    // fully connected: the own slice goes straight to every peer and every peer's slice comes straight back, all in one
-    // RCCL group — one hop over the 7 xGMI links at once instead of P-1 ring hops
-    NCCLC(g_rccl.GroupStart());
-    for (int s = 1; s < P; ++s) {
-      const int to = (L.rank + s) % P, from = ring_slice(L.rank, s);
-      const int fr = slice_first(from, g.n, P), lr = slice_first(from + 1, g.n, P) - fr;
-      NCCLC(g_rccl.Send(word_ptr(dev_full, L.first), (size_t)L.n_local * wb, ncclChar, to, L.comm_h, L.comm));
-      NCCLC(g_rccl.Recv(word_ptr(dev_full, fr), (size_t)lr * wb, ncclChar, from, L.comm_h, L.comm));
-    }
-    NCCLC(g_rccl.GroupEnd());
-    if (ev) for (int s = 1; s < P; ++s) HIPC(hipEventRecord(ev[s], L.comm));
-    return NBODY_OK;
+  std::vector<CommOp> ops;
+  NBC(comm_plan(form, L.rank, P, g.n, ops));
+  const int groups = ops.empty() ? 0 : ops.back().group;
+  for (int grp = 1; grp <= groups; ++grp) {
+    NBC(run_plan_group(L, dev_full, ops, grp));
+    if (ev && form == NBODY_COMM_RING) HIPC(hipEventRecord(ev[grp], L.comm));
   }
-  for (int s = 1; s < P; ++s) {
-    const int qs = ring_slice(L.rank, s - 1);   // forward what arrived last (own slice at s = 1)
-    const int qr = ring_slice(L.rank, s);
-    const int fs = slice_first(qs, g.n, P), ls = slice_first(qs + 1, g.n, P) - fs;
-    const int fr = slice_first(qr, g.n, P), lr = slice_first(qr + 1, g.n, P) - fr;
-    NBC(ring_step(L, word_ptr(dev_full, fs), (size_t)ls * wb, word_ptr(dev_full, fr), (size_t)lr * wb));
-    if (ev) HIPC(hipEventRecord(ev[s], L.comm));
-  }
+  if (ev && form != NBODY_COMM_RING) for (int s = 1; s < P; ++s) HIPC(hipEventRecord(ev[s], L.comm));
   return NBODY_OK;
 }
 
@@ -522,8 +647,23 @@ int enqueue_gather(int buf) {
   return rccl_gather(L, L.pos[buf], L.ev_gather);
 }
 
+// the compute stream waits for an arriving slice: timed (NBODY_OPT_TIMING) as exposed communication — the span between
+// the moment the stream has nothing else to do and the moment the slice's event fires
+int wait_for_slice(Local& L, hipEvent_t ev) {
+  int slot;
+  NBC(timer_begin(L.wait, L.compute, &slot));
+  HIPC(hipStreamWaitEvent(L.compute, ev, 0));
+  return timer_end(L.wait, L.compute, slot);
+}
+
+int enqueue_step_impl(float dt, double dt64);
 // One step on every local: forces on pos[cur], kick, drift into pos[cur^1], swap.
 int enqueue_step(float dt, double dt64) {
+  const int rc = enqueue_step_impl(dt, dt64);
+  if (rc) g.tickets_dirty = true;   // some launches of the step may have run: reconfigure() re-zeroes the arrival counters
+  return rc;
+}
+int enqueue_step_impl(float dt, double dt64) {
   const int P = g.nranks;
   const Finish fin = {true, true, false};
   const bool need_gather = !g.loc[0].all_present;
@@ -551,16 +691,16 @@ int enqueue_step(float dt, double dt64) {
     } else if (g.opt.overlap == 2) {
       // one launch per arriving slice, each released by that slice's event (ring arrival order)
       for (int s = 1; s < P; ++s) {
-        HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[s], 0));
+        NBC(wait_for_slice(L, L.ev_gather[s]));
         NBC(launch_force(L, 0, L.n_local, ring_slice(L.rank, s), 1, fin, dt, dt64));
       }
     } else if (g.opt.overlap) {
-      // the other slices in one launch once they have all arrived (at N = 1M the ring takes ~0.4 ms against
-      // ~4 ms of own-slice work already running)
-      HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[P - 1], 0));
+      // the other slices in one launch once they have all arrived (N = 1M, P = 8: 14 MiB of transfers against
+      // ~3.7 ms of own-slice work already running; what is not hidden shows up in nbody_comm_time)
+      NBC(wait_for_slice(L, L.ev_gather[P - 1]));
       NBC(launch_force(L, 0, L.n_local, ring_slice(L.rank, 1), P - 1, fin, dt, dt64));
     } else {
-      HIPC(hipStreamWaitEvent(L.compute, L.ev_gather[P - 1], 0));
+      NBC(wait_for_slice(L, L.ev_gather[P - 1]));
       NBC(launch_force(L, 0, L.n_local, L.rank, P, fin, dt, dt64));
     }
     NBC(launch_combine(L, 0, L.n_local, fin, dt, dt64));
@@ -637,7 +777,8 @@ void free_local(Local& L) {
   if (L.full_scratch) (void)hipFree(L.full_scratch);
   if (L.ev_own_ready) (void)hipEventDestroy(L.ev_own_ready);
   for (int s = 0; s < kMaxRanks; ++s) if (L.ev_gather[s]) (void)hipEventDestroy(L.ev_gather[s]);
-  for (int k = 0; k < kTimerRing; ++k) { if (L.t0[k]) (void)hipEventDestroy(L.t0[k]); if (L.t1[k]) (void)hipEventDestroy(L.t1[k]); }
+  for (EventTimer* T : {&L.kern, &L.wait})
+    for (int k = 0; k < kTimerRing; ++k) { if (T->t0[k]) (void)hipEventDestroy(T->t0[k]); if (T->t1[k]) (void)hipEventDestroy(T->t1[k]); }
   if (L.compute) (void)hipStreamDestroy(L.compute);
   if (L.comm) (void)hipStreamDestroy(L.comm);
   L = Local();
@@ -653,9 +794,12 @@ int upload_impl(const void* pos, const void* vel) {
     HIPC(hipSetDevice(L.device));
     HIPC(hipMemcpyAsync(L.pos[L.cur], pos, (size_t)g.n * wb, hipMemcpyHostToDevice, L.compute));
     HIPC(hipMemcpyAsync(L.vel, (const char*)vel + (size_t)L.first * wb, (size_t)L.n_local * wb, hipMemcpyHostToDevice, L.compute));
+    // a fresh state starts from clean arrival counters whatever happened before (a failed step leaves them part-counted)
+    HIPC(hipMemsetAsync(L.tickets, 0, ticket_words(L) * sizeof(unsigned), L.compute));
     HIPC(hipEventRecord(L.ev_own_ready, L.compute));
     L.all_present = true;
   }
+  g.tickets_dirty = false;
   return sync_all();
 }
 
@@ -700,19 +844,29 @@ int download_impl(void* pos, void* vel) {
   return NBODY_OK;
 }
 
-// forces of rows [row0, row0+count) of every local's slice, from pos[cur] (must be complete)
-int forces_on_device(int row0, int count_or_all) {
+// forces of the GLOBAL bodies [g0, g0 + count) (count < 0: all), each local for the part that lies in its slice, from
+// pos[cur] (made complete first)
+int forces_on_device_impl(int g0, int count) {
   NBC(reconfigure());
   NBC(complete_positions());
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
-    int cnt = count_or_all < 0 ? L.n_local : count_or_all;
-    int r0 = count_or_all < 0 ? 0 : row0;
+    int r0 = 0, cnt = L.n_local;
+    if (count >= 0) {
+      const int b = std::max(g0, L.first), e = std::min(g0 + count, L.first + L.n_local);
+      if (e <= b) continue;
+      r0 = b - L.first; cnt = e - b;
+    }
     const Finish fin = {false, false, true};
     NBC(launch_force(L, r0, cnt, g.nslices - 1, g.nslices, fin, 0.f, 0.0));
     NBC(launch_combine(L, r0, cnt, fin, 0.f, 0.0));
   }
   return sync_all();
+}
+int forces_on_device(int g0, int count) {
+  const int rc = forces_on_device_impl(g0, count);
+  if (rc) g.tickets_dirty = true;
+  return rc;
 }
 
 int step_impl(float dt, double dt64, int nsteps) {
@@ -764,8 +918,9 @@ int body_force_impl(void* pos, void* vel, float dt, double dt64, int n) {
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
     const Finish fin = {true, false, true};
-    NBC(launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fin, dt, dt64));
-    NBC(launch_combine(L, 0, L.n_local, fin, dt, dt64));
+    int rc = launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fin, dt, dt64);
+    if (!rc) rc = launch_combine(L, 0, L.n_local, fin, dt, dt64);
+    if (rc) { g.tickets_dirty = true; return rc; }
   }
   NBC(sync_all());
   // vel back (pos is read-only for bodyForce)
@@ -844,14 +999,24 @@ int forces_impl(const void* pos_words, void* force_words, int n) {
   return NBODY_OK;
 }
 
+// first_row: nbody_init contexts (one process, one or several devices): GLOBAL body index, the range may span devices;
+// nbody_init_rank contexts: row of this rank's own slice.
 int forces_rows_impl(int first_row, int n_rows, void* force_words) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
-  if (g.nlocal != 1 || !force_words) return NBODY_ERR_UNSUPPORTED;
-  Local& L = g.loc[0];
-  if (first_row < 0 || n_rows <= 0 || first_row + n_rows > L.n_local) return NBODY_ERR_ARG;
-  NBC(forces_on_device(first_row, n_rows));
-  HIPC(hipSetDevice(L.device));
-  HIPC(hipMemcpy(force_words, word_ptr(L.force, first_row), (size_t)n_rows * word_bytes(), hipMemcpyDeviceToHost));
+  if (!force_words) return NBODY_ERR_ARG;
+  const int base = g.multiprocess ? g.loc[0].first : 0;
+  const int limit = g.multiprocess ? g.loc[0].n_local : g.n;
+  if (first_row < 0 || n_rows <= 0 || first_row + n_rows > limit) return NBODY_ERR_ARG;
+  const int g0 = base + first_row;
+  NBC(forces_on_device(g0, n_rows));
+  const size_t wb = word_bytes();
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    const int b = std::max(g0, L.first), e = std::min(g0 + n_rows, L.first + L.n_local);
+    if (e <= b) continue;
+    HIPC(hipSetDevice(L.device));
+    HIPC(hipMemcpy((char*)force_words + (size_t)(b - g0) * wb, word_ptr(L.force, b - L.first), (size_t)(e - b) * wb, hipMemcpyDeviceToHost));
+  }
   return NBODY_OK;
 }
 
@@ -1018,6 +1183,132 @@ int nbody_comm_selftest(long long* bytes_moved) {
   return NBODY_OK;
 }
 
+// The transfer plans of `vp` VIRTUAL ranks (an N-body job of vp ranks over g.n bodies, ragged slices included) executed
+// through real ncclSend/ncclRecv on this one-rank communicator: every virtual rank has its own N-word array on the device
+// holding only its own slice; group by group, each receive of each virtual rank is issued together with the send its peer's
+// plan pairs with it (same group, send_peer = the receiver) — with one real rank all peers are "self" and RCCL matches
+// the k-th send with the k-th receive of a group, so issuing them pairwise reproduces exactly the P-rank exchange.
+// Afterwards every array must hold all N words.  This runs the plan's offsets, byte counts and send/recv pairing of both
+// forms on hardware, which a one-rank job's own plan (P - 1 = 0 pairs) never does.
+int nbody_comm_selftest_virtual(int vp, int form, long long* bytes_moved) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!g.multiprocess || g.nranks != 1) return NBODY_ERR_STATE;
+  Local& L = g.loc[0];
+  if (!L.comm_h) return NBODY_ERR_STATE;
+  if (vp < 2 || vp > 16 || g.n < vp || (form != NBODY_COMM_RING && form != NBODY_COMM_DIRECT)) return NBODY_ERR_ARG;
+  NBC(sync_all());
+  const size_t wb = word_bytes(), lanes = wb / 4;
+  HIPC(hipSetDevice(L.device));
+  struct Bufs {   // freed on every way out
+    std::vector<void*> d;
+    ~Bufs() { for (void* p : d) if (p) (void)hipFree(p); }
+  } bufs;
+  bufs.d.assign(vp, nullptr);
+  std::vector<std::vector<CommOp>> plan(vp);
+  std::vector<uint32_t> host((size_t)g.n * lanes);
+  auto pattern = [](int w, size_t k) { return 0x5A000000u ^ ((uint32_t)w * 4u + (uint32_t)k) * 2654435761u; };
+  for (int r = 0; r < vp; ++r) {
+    NBC(comm_plan(form, r, vp, g.n, plan[r]));
+    HIPC(hipMalloc(&bufs.d[r], (size_t)(g.n + 64) * wb));
+    HIPC(hipMemset(bufs.d[r], 0xff, (size_t)g.n * wb));
+    const int f = slice_first(r, g.n, vp), c = slice_first(r + 1, g.n, vp) - f;
+    for (int w = f; w < f + c; ++w) for (size_t k = 0; k < lanes; ++k) host[(size_t)w * lanes + k] = pattern(w, k);
+    HIPC(hipMemcpy(word_ptr(bufs.d[r], f), &host[(size_t)f * lanes], (size_t)c * wb, hipMemcpyHostToDevice));
+  }
+  long long moved = 0;
+  const int groups = plan[0].empty() ? 0 : plan[0].back().group;
+  for (int grp = 1; grp <= groups; ++grp) {
+    NCCLC(g_rccl.GroupStart());
+    for (int r = 0; r < vp; ++r) {
+      for (const CommOp& o : plan[r]) {
+        if (o.group != grp) continue;
+        // the send that rank o.recv_peer's plan pairs with this receive: same group, addressed to r, same word range
+        const CommOp* snd = nullptr;
+        for (const CommOp& q : plan[o.recv_peer])
+          if (q.group == grp && q.send_peer == r && q.send_first == o.recv_first && q.send_count == o.recv_count) { snd = &q; break; }
+        if (!snd) { (void)g_rccl.GroupEnd(); g_last_line = __LINE__; return NBODY_ERR_STATE; }   // the plans do not pair up
+        NCCLC(g_rccl.Send(word_ptr(bufs.d[o.recv_peer], (size_t)snd->send_first), (size_t)snd->send_count * wb, ncclChar, 0, L.comm_h, L.comm));
+        NCCLC(g_rccl.Recv(word_ptr(bufs.d[r], (size_t)o.recv_first), (size_t)o.recv_count * wb, ncclChar, 0, L.comm_h, L.comm));
+        moved += o.recv_count * (long long)wb;
+      }
+    }
+    NCCLC(g_rccl.GroupEnd());
+  }
+  HIPC(hipStreamSynchronize(L.comm));
+  for (int r = 0; r < vp; ++r) {
+    HIPC(hipMemcpy(host.data(), bufs.d[r], (size_t)g.n * wb, hipMemcpyDeviceToHost));
+    for (int w = 0; w < g.n; ++w)
+      for (size_t k = 0; k < lanes; ++k)
+        if (host[(size_t)w * lanes + k] != pattern(w, k)) { g_last_line = __LINE__; return NBODY_ERR_STATE; }
+  }
+  if (bytes_moved) *bytes_moved = moved;
+  return NBODY_OK;
+}
+
+// The plan of rank `rank` of `nranks` over n bodies in form NBODY_COMM_RING or NBODY_COMM_DIRECT, 7 values per pair:
+// {group, send_peer, send_first_word, send_words, recv_peer, recv_first_word, recv_words}.  Pure host arithmetic (no GPU,
+// no context): what rccl_gather() executes.  *n_ops = pairs (nranks - 1); ops may be NULL to ask for the count.
+int nbody_comm_plan(int form, int rank, int nranks, int n, long long* ops, int max_ops, int* n_ops) {
+  std::vector<CommOp> v;
+  NBC(comm_plan(form, rank, nranks, n, v));
+  if (n_ops) *n_ops = (int)v.size();
+  if (!ops) return NBODY_OK;
+  if ((int)v.size() > max_ops) return NBODY_ERR_ARG;
+  for (size_t k = 0; k < v.size(); ++k) {
+    long long* o = ops + 7 * k;
+    o[0] = v[k].group; o[1] = v[k].send_peer; o[2] = v[k].send_first; o[3] = v[k].send_count;
+    o[4] = v[k].recv_peer; o[5] = v[k].recv_first; o[6] = v[k].recv_count;
+  }
+  return NBODY_OK;
+}
+
+// How long one RCCL ring step of `bytes` (ncclSend to rank+1 / ncclRecv from rank-1, one group) takes on the transfer
+// stream, from the moment it is enqueued: alone (when = 0), enqueued just BEFORE a full force pass on the compute stream
+// (when = 1) or just AFTER it (when = 2) — the force launch fills every wave slot of every CU, so this is what a
+// transfer costs beside it.  *comm_ms: enqueue -> done on the transfer stream (HIP events); *force_ms: the force pass.
+int nbody_comm_probe(long long bytes, int when, double* comm_ms, double* force_ms) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (!g.multiprocess) return NBODY_ERR_STATE;
+  Local& L = g.loc[0];
+  if (!L.comm_h) return NBODY_ERR_STATE;
+  const size_t wb = word_bytes();
+  if (bytes <= 0 || when < 0 || when > 2 || (size_t)bytes * 2 > (size_t)g.n * wb) return NBODY_ERR_ARG;
+  NBC(reconfigure());
+  NBC(complete_positions());
+  NBC(sync_all());
+  HIPC(hipSetDevice(L.device));
+  if (!L.full_scratch) HIPC(hipMalloc(&L.full_scratch, (size_t)(g.n + 64) * wb));
+  struct Ev4 { hipEvent_t e[4] = {}; ~Ev4() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } ev;
+  for (hipEvent_t& x : ev.e) HIPC(hipEventCreate(&x));
+  const Finish fin = {false, false, true};
+  auto force_pass = [&]() -> int {
+    HIPC(hipEventRecord(ev.e[2], L.compute));
+    int rc = launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fin, 0.f, 0.0);
+    if (!rc) rc = launch_combine(L, 0, L.n_local, fin, 0.f, 0.0);
+    if (rc) { g.tickets_dirty = true; return rc; }
+    HIPC(hipEventRecord(ev.e[3], L.compute));
+    return NBODY_OK;
+  };
+  auto comm_step = [&]() -> int {
+    HIPC(hipEventRecord(ev.e[0], L.comm));
+    NBC(ring_step(L, L.full_scratch, (size_t)bytes, (char*)L.full_scratch + bytes, (size_t)bytes));
+    HIPC(hipEventRecord(ev.e[1], L.comm));
+    return NBODY_OK;
+  };
+  if (when == 1) { NBC(comm_step()); NBC(force_pass()); }
+  else if (when == 2) { NBC(force_pass()); NBC(comm_step()); }
+  else NBC(comm_step());
+  NBC(sync_all());
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
+  if (comm_ms) *comm_ms = ms;
+  if (force_ms) {
+    *force_ms = 0.0;
+    if (when) { HIPC(hipEventElapsedTime(&ms, ev.e[2], ev.e[3])); *force_ms = ms; }
+  }
+  return NBODY_OK;
+}
+
 void nbody_shutdown(void) {
   drop_step_graph();
   for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);
@@ -1043,7 +1334,14 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;
     case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
-    case NBODY_OPT_ISA_PHASE: if (value < 0 || value > 18) return NBODY_ERR_ARG; g.opt.isa_phase = value; break;
+    case NBODY_OPT_ISA_PHASE:
+      if (value < 0 || value > 18) return NBODY_ERR_ARG;
+#ifndef NBODY_DIAG_LOOPS
+      // experiment encodings and timing-only forms (wrong results) are not in the product library: `make diag`
+      if (isa_phase_is_diag(value) && !(g.init && g.fp64 && value == 2)) return NBODY_ERR_UNSUPPORTED;
+#endif
+      g.opt.isa_phase = value; break;
+    case NBODY_OPT_WSPLIT: if (value != -1 && value != 1 && value != 4) return NBODY_ERR_ARG; g.opt.wsplit = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); drop_step_graph(); return reconfigure(); }
@@ -1078,6 +1376,19 @@ int nbody_get_info(int key, long long* value) {
       break;
     }
     case NBODY_INFO_HAS_COMM: *value = L.comm_h ? 1 : 0; break;
+    case NBODY_INFO_WSPLIT: *value = g.wsplit; break;
+    case NBODY_INFO_ISA_PHASE: *value = g.opt.isa_phase; break;
+    case NBODY_INFO_LONG_BUFFERS: *value = g.opt.long_buffers; break;
+    case NBODY_INFO_XCD_MAP: *value = g.opt.xcd_map; break;
+    case NBODY_INFO_FUSE_COMBINE: *value = g.fuse; break;
+    case NBODY_INFO_COMM_FORM: *value = g.nranks > 1 ? resolved_comm_form() : -1; break;
+    case NBODY_INFO_COMM_PRIORITY: *value = g.comm_priority; break;
+    case NBODY_INFO_DIAG_BUILD:
+#ifdef NBODY_DIAG_LOOPS
+      *value = 1; break;
+#else
+      *value = 0; break;
+#endif
     default: return NBODY_ERR_ARG;
   }
   return NBODY_OK;
@@ -1174,13 +1485,29 @@ int nbody_kernel_time(double* ms_total, long long* launches, int reset) {
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
     HIPC(hipSetDevice(L.device));
-    NBC(timer_drain(L, 0));
-    ms = std::max(ms, L.t_ms);   // locals run concurrently: report the slowest device
-    n += L.t_launches;
-    if (reset) { L.t_ms = 0.0; L.t_launches = 0; }
+    NBC(timer_drain(L.kern, 0));
+    ms = std::max(ms, L.kern.ms);   // locals run concurrently: report the slowest device
+    n += L.kern.n;
+    if (reset) { L.kern.ms = 0.0; L.kern.n = 0; }
   }
   if (ms_total) *ms_total = ms;
   if (launches) *launches = n;
+  return NBODY_OK;
+}
+
+int nbody_comm_time(double* wait_ms_total, long long* waits, int reset) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  double ms = 0.0; long long n = 0;
+  for (int l = 0; l < g.nlocal; ++l) {
+    Local& L = g.loc[l];
+    HIPC(hipSetDevice(L.device));
+    NBC(timer_drain(L.wait, 0));
+    ms = std::max(ms, L.wait.ms);
+    n += L.wait.n;
+    if (reset) { L.wait.ms = 0.0; L.wait.n = 0; }
+  }
+  if (wait_ms_total) *wait_ms_total = ms;
+  if (waits) *waits = n;
   return NBODY_OK;
 }
 

@@ -58,11 +58,11 @@ constexpr int kFinishLast = 2;     // store the partial sum (write-through); the
 struct ForceArgs {
   const void* src;      // all N source bodies (16-B or 32-B words), ascending
   const void* rows;     // the rank's own bodies: rows[i] = src[first_body + i]
-  void* partial;        // [nseg][n_rows] words {Fx,Fy,Fz,0}
+  void* partial;        // [nseg][part_stride] words {Fx,Fy,Fz,0}, rows counted from row0 (launch-relative)
   void* vel;            // [n_rows]
   void* pos_next_rows;  // [n_rows]
   void* force_out;      // [n_rows] {Fx,Fy,Fz,0} (S/compute_store.vhd:242) or null
-  unsigned* tickets;    // four counters per block of rows, one per wave (kFinishLast); zero between steps
+  unsigned* tickets;    // one arrival counter per 64 rows counted from row0 (kFinishLast); zero between steps
   int n_src;            // N
   int n_rows;           // bodies owned by this rank
   int row0;             // first row handled by this launch (nbody_forces_rows)
@@ -76,6 +76,12 @@ struct ForceArgs {
   int long_buffers;     // ISA variant: 8-body scalar buffers (launches with < 4 waves per SIMD, see tools/gen_force_loop.py)
   int xcd_map;          // 1: workgroups that share an XCD (linear id mod 8) take the same source segments, see block_segment()
   int fpga16;           // 1: S/fxyz.vhd:129-184 + S/final_adder.vhd:88-104 summation order inside a segment
+  int wsplit;           // 1: a workgroup owns 256*R rows and its four waves walk the same segment for different rows;
+                        // 4: a workgroup owns 64 rows and wave w walks piece w of 4 of the segment for those same rows — the four
+                        //    sums are added through LDS in ascending source order (a third level of the sum), so a launch of
+                        //    the same workgroup count has a quarter of the global partial sums, tickets and last-arriver rounds
+  int part_stride;      // words between two segments' rows in `partial`: row_count rounded up to 64, so that the 1 KiB (2 KiB in
+                        // fp64) regions of different waves/workgroups never share a cache line
   float dt;
   double dt64;
 };
@@ -95,6 +101,17 @@ __device__ __host__ inline void segment_bounds(int q, int t, int n, int P, int s
   if (b > f1) b = f1;
   if (e > f1) e = f1;
   *jb = b; *je = e;
+}
+
+// piece w of `ws` of the segment [jb, je): what wave w of a workgroup walks when ForceArgs::wsplit = ws (same cut as
+// a slice into pieces: ceil(len / ws) sources each, the last ones possibly shorter or empty)
+__device__ __host__ inline void piece_bounds(int jb, int je, int w, int ws, int* pb, int* pe) {
+  int piece = (je - jb + ws - 1) / ws;
+  int b = jb + w * piece;
+  int e = b + piece;
+  if (b > je) b = je;
+  if (e > je) e = je;
+  *pb = b; *pe = e;
 }
 
 // v_readlane_b32: the value lane k holds, as a wave-uniform scalar.  Takes the float BY VALUE:
@@ -245,12 +262,18 @@ template <typename Args>   // ForceArgs by value or in the kernel-argument segme
 __device__ __forceinline__ void wg_coords(const Args& a, int* rb, int* y) {
   *y = blockIdx.y;
   *rb = blockIdx.x;
-  if (a.xcd_map) {   // the host sets it only when gridDim.y % 8 == 0
-    const unsigned X = gridDim.x;
-    const unsigned linear = blockIdx.y * X + blockIdx.x, slot = linear >> 3;
-    const unsigned m = slot / X;
-    *y = (int)((linear & 7u) + 8u * m);
-    *rb = (int)(slot - m * X);
+  if (a.xcd_map) {   // the host sets it only when gridDim.y % 8 == 0, or 8 % gridDim.y == 0 and gridDim.x % (8 / gridDim.y) == 0
+    const unsigned X = gridDim.x, Y = gridDim.y;
+    const unsigned linear = blockIdx.y * X + blockIdx.x, slot = linear >> 3, xcd = linear & 7u;
+    if ((Y & 7u) == 0) {
+      const unsigned m = slot / X;
+      *y = (int)(xcd + 8u * m);
+      *rb = (int)(slot - m * X);
+    } else {           // Y = 1, 2 or 4 segment rows: XCD x takes row y = x mod Y; the 8 / Y XCDs of a row deal its row blocks
+      const unsigned per = 8u / Y;
+      *y = (int)(xcd % Y);
+      *rb = (int)(slot * per + xcd / Y);
+    }
   }
 }
 
@@ -281,16 +304,32 @@ __device__ __forceinline__ V4 load_word_sc1(__amdgpu_buffer_rsrc_t rs, int off) 
   }
 }
 
-// Finish the R rows of a lane (rows lane_row + r*kBlock, valid below row_end) given the segment's sums.
+// Finish the R rows of a lane (rows lane_row + r*kBlock, valid below row_end) given the sums of what this wave walked.
+//   WS = 4 first (ForceArgs::wsplit): the four waves of the workgroup hold the sums of the four pieces of ONE segment for the
+//                  same 64 rows.  Waves 1..3 put theirs into LDS, one barrier, and wave 0 adds them to its own in ascending
+//                  source order, ((w0 + w1) + w2) + w3 — the third level of the sum, restated by the oracle (ref_order_t::wsplit).
+//                  Only wave 0 goes on; the workgroup then is one 64-row unit with one partial sum per segment.
 //   kFinishDirect  apply them.
 //   kFinishStore   store them as this segment's partial; combine_kernel adds the segments later.
-//   kFinishLast    the split-reduction hand-off inside one launch, wave by wave (no workgroup barrier: the four waves of a
-//                  workgroup own disjoint rows).  Every wave stores its partial sums with write-through (sc1) stores, drains
-//                  them (s_waitcnt vmcnt(0)), and ONE lane takes a ticket with an agent-scope atomic add on the counter of
-//                  (row block, wave).  The wave whose ticket is the last of the nseg (over all launches of the step) learns
+//   kFinishLast    the split-reduction hand-off inside one launch, wave by wave (no workgroup barrier: with WS = 1 the four waves
+//                  of a workgroup own disjoint rows).  Every wave stores its partial sums with write-through (sc1) stores, drains
+//                  them (s_waitcnt vmcnt(0)), and ONE lane takes a ticket with an agent-scope atomic add on the counter of its
+//                  64 rows.  The wave whose ticket is the last of the nseg (over all launches of the step) learns
 //                  that from the returned value, and its lanes read the nseg partials of their rows with sc1 loads IN
 //                  ASCENDING SEGMENT ORDER — so the result is the same whichever wave arrives last — apply them and zero
 //                  the ticket for the next step.  Nothing ever waits on another wave.
+//                  Visibility relied on (MI355X_MICROARCH.md, inter-workgroup visibility; the compiled sequence is LLVM's own
+//                  agent-scope release/acquire for gfx942+: `buffer_store ... sc1` -> `s_waitcnt vmcnt(0)` -> `global_atomic_add`
+//                  (agent scope: performed at memory, past every L2) -> `buffer_inv sc1` -> `buffer_load ... sc1`):
+//                    (1) an sc1 store is written through the issuing XCD's L2 to memory, and vmcnt reaches 0 only when that
+//                        write is acknowledged — so a partial sum is in memory before its wave's ticket is;
+//                    (2) the ticket is one memory location for all XCDs (device-scope atomics are not cached in a non-coherent
+//                        L2), so exactly one wave sees nseg - 1 and every other wave's add — hence its stores — precedes it;
+//                    (3) `buffer_inv sc1` drops the reader's L1 and its XCD's non-coherent L2 lines, and an sc1 load misses
+//                        both, so the reader fetches what (1) wrote.  The regions of different tickets never share a cache line
+//                        (ForceArgs::part_stride, launch-relative rows: 1 KiB-aligned), so no line can be half stale.
+//                  None of this depends on how many workgroups share a CU (the guide measured one per CU; here eight):
+//                  the guarantees are per store/atomic/load, not per CU.  tests: test_one_launch_combine_equals_combine_kernel.
 //
 // The arguments are re-read here from the kernel-argument segment (every force kernel takes one ForceArgs by value, at
 // offset 0 of it) instead of being kept in SGPRs through the source loop, where the two scalar-load buffers of the
@@ -300,8 +339,21 @@ __device__ __forceinline__ V4 load_word_sc1(__amdgpu_buffer_rsrc_t rs, int off) 
 // every other wave has left — and it is latency-bound: nseg / CF rounds of ~0.8 us (per-wave timestamps at N = 16384: all
 // source loops over at 62-63 us, the last arrivers done at 70.5 with 8 in flight; profiles/r02_small_n.md).  The kernel's
 // VGPR budget decides how many fit, 4 per partial in fp32 (hipcc splits a 12-byte load into dword loads in three passes).
-template <typename T, typename V4, int R, int CF = 0>
-__device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, const V4 (&me)[R], const Sums<T, R>& s) {
+template <typename T, typename V4, int R, int WS, int CF = 0>
+__device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, const V4 (&me)[R], Sums<T, R>& s, V4 (*ws)[64]) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  if constexpr (WS > 1) {
+    static_assert(R == 1, "the wave split is for one body per lane");
+    if (wave > 0) { V4 o = {s.bx[0], s.by[0], s.bz[0], (T)0}; ws[wave - 1][lane] = o; }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int k = 0; k < WS - 1; ++k) {     // ascending source order: piece 1, 2, 3 onto piece 0
+      const V4 p = ws[k][lane];
+      s.bx[0] = s.bx[0] + p.x; s.by[0] = s.by[0] + p.y; s.bz[0] = s.bz[0] + p.z;
+    }
+  }
   const NB_CONST ForceArgs* ka = (const NB_CONST ForceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ka));   // opaque from here on: the loads below cannot move above the source loop
   const NB_CONST ForceArgs& a = *ka;
@@ -318,18 +370,18 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
     for (int r = 0; r < R; ++r) {
       const int i = lane_row + r * kBlock;
       V4 o = {s.bx[r], s.by[r], s.bz[r], (T)0};   // S/compute_store.vhd:242 {0, Fz, Fy, Fx}
-      if (i < row_end) ((V4*)a.partial)[(size_t)seg * a.n_rows + i] = o;
+      if (i < row_end) ((V4*)a.partial)[(size_t)seg * a.part_stride + (i - a.row0)] = o;
     }
     return;
   }
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int kWgRows = WS > 1 ? 64 : kBlock * R;
   int row_block, y_unused;
   wg_coords(a, &row_block, &y_unused);   // recomputed from the re-read arguments rather than kept in SGPRs through the source loop
-  const int wg_row0 = a.row0 + row_block * (kBlock * R);             // wave-uniform: first row of this workgroup
-  const int wg_rows = min(kBlock * R, row_end - wg_row0);
-  const int lane_off = (int)(threadIdx.x * sizeof(V4));
+  const int wg_rel0 = row_block * kWgRows;                              // wave-uniform: first row of this workgroup, from row0
+  const int wg_rows = min(kWgRows, a.row_count - wg_rel0);
+  const int lane_off = (WS > 1 ? lane : (int)threadIdx.x) * (int)sizeof(V4);
   {
-    char* base = (char*)a.partial + ((size_t)seg * a.n_rows + wg_row0) * sizeof(V4);
+    char* base = (char*)a.partial + ((size_t)seg * a.part_stride + wg_rel0) * sizeof(V4);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, wg_rows * (int)sizeof(V4), 0x00020000);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -338,14 +390,12 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached memory before its ticket is taken
-  unsigned* ticket = a.tickets + (size_t)row_block * 4 + wave;
+  unsigned* ticket = a.tickets + (size_t)(wg_rel0 >> 6) + (WS > 1 ? 0 : wave);
   unsigned t = 0;
-  if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
   if (t != (unsigned)(a.nseg - 1)) return;
-  // The partials are read with sc1 loads only (they bypass this CU's L1, the one cache another wave's stores never
-  // refresh), which is what makes them visible; the agent-scope acquire is issued as well (it completes in the
-  // background: the loads below do not depend on it).
+  // agent-scope acquire (buffer_inv sc1), then the partials with sc1 loads only: see (3) above
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   T fx[R], fy[R], fz[R];
   // CF > 0 (the hand-scheduled fp32 kernels, which have the registers): the rows' velocities travel with the first round of
@@ -365,7 +415,7 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       if (sg0 + k < a.nseg) {
-        char* base = (char*)a.partial + ((size_t)(sg0 + k) * a.n_rows + wg_row0) * sizeof(V4);
+        char* base = (char*)a.partial + ((size_t)(sg0 + k) * a.part_stride + wg_rel0) * sizeof(V4);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, wg_rows * (int)sizeof(V4), 0x00020000);
 #pragma unroll
         for (int r = 0; r < R; ++r) p[k][r] = load_word_sc1<V4>(rs, lane_off + r * kBlock * (int)sizeof(V4));
@@ -390,7 +440,7 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
       else apply_force<T, V4>(a, i, me[r], fx[r], fy[r], fz[r]);
     }
   }
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Which rows and which source segment a workgroup takes.  The hardware deals workgroups round-robin over the 8 XCDs in
@@ -423,17 +473,35 @@ __device__ __forceinline__ void load_rows(const ForceArgs& a, int lane_row, int 
   }
 }
 
+// What a wave works on: its lane's first row and the sources it walks.  WS = 1: the workgroup's 256*R rows, the whole
+// segment.  WS = 4: the workgroup's 64 rows (lane l of every wave owns the same row), piece `wave` of the segment.
+template <int R, int WS>
+__device__ __forceinline__ void wave_work(const ForceArgs& a, int* seg, int* jb, int* je, int* lane_row) {
+  int rb;
+  block_segment(a, seg, jb, je, &rb);
+  if constexpr (WS > 1) {
+    static_assert(R == 1, "the wave split is for one body per lane");
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    piece_bounds(*jb, *je, wave, WS, jb, je);
+    *lane_row = a.row0 + rb * 64 + (int)(threadIdx.x & 63);
+  } else {
+    *lane_row = a.row0 + rb * (kBlock * R) + (int)threadIdx.x;
+  }
+}
+// LDS words of the wave split's hand-over (3 waves x 64 rows); one dummy word when the kernel does not split
+#define NB_WS_LDS(V4, WS) __shared__ V4 ws_sums[(WS) > 1 ? (WS) - 1 : 1][64]
+
 // ---------------------------------------------------------------------------
 // SMEM variant.  The source words are read with scalar loads (8 bodies = two
 // s_load_dwordx16 per group), land in SGPRs and feed the VALU as scalar
 // operands: no LDS traffic, no barrier, no VALU instruction spent on the
 // broadcast.  Groups are double-buffered by hand (load group g+1, compute g).
-template <int R, int ARITH>
+template <int R, int ARITH, int WS>
 __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
-  int seg, jb, je, rb;
-  block_segment(a, &seg, &jb, &je, &rb);
+  NB_WS_LDS(f4, WS);
+  int seg, jb, je, lane_row;
+  wave_work<R, WS>(a, &seg, &jb, &je, &lane_row);
   const float eps = soft_f32();
-  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[R];
   load_rows<float, f4, R>(a, lane_row, row_end, me);
@@ -471,7 +539,7 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
       for (int r = 0; r < R; ++r) pair_f32<ARITH>(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
     }
   });
-  finish_rows<float, f4, R>(seg, lane_row, row_end, me, s);
+  finish_rows<float, f4, R, WS>(seg, lane_row, row_end, me, s, ws_sums);
 }
 
 // ---------------------------------------------------------------------------
@@ -486,16 +554,15 @@ __global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
 // SGPR budgets: 81-96 SGPRs leave room for 7 waves per SIMD, <= 80 for 8 (MI355X_MICROARCH.md, "Occupancy API" row).  The
 // product loop's scalars end at s72 (79 with VCC etc.: 8 waves); the long-buffer loop holds 64 buffer SGPRs (106: 6 waves),
 // which is why it is a kernel of its own.
-template <int PLACEMENT, int LONG>
-__device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
-  int seg, jb, je, rb;
-  block_segment(a, &seg, &jb, &je, &rb);
+template <int PLACEMENT, int LONG, int WS>
+__device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_sums)[64]) {
+  int seg, jb, je, i;
+  wave_work<1, WS>(a, &seg, &jb, &je, &i);
   const float eps = soft_f32();
-  const int i = a.row0 + rb * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
   const int count = je - jb;
-  // Touch the scalar-cache lines of the segment's first sources now, so that they travel together with the row load:
+  // Touch the scalar-cache lines of the wave's first sources now, so that they travel together with the row load:
   // the loop's own first s_load is issued only after the wait for xi, yi, zi (one memory latency saved per wave,
   // which is what a short segment at small N feels).
   // (one dword each, unconditional: jb + 4 stays inside the arrays' 64-word pad; no branch and no register reuse, so
@@ -516,68 +583,62 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
   const int blk = blocked ? a.sum_block / group : 0x7fffffff;
   if (groups > 0) {
     const uint64_t p = (uint64_t)(uintptr_t)a.src + (uint64_t)jb * sizeof(f4);
-    if constexpr (LONG) {   // its own kernel: the 64 buffer SGPRs would cost the product loop its 8th resident wave
-      asm volatile(NB_FORCE_LOOP_LONG
-                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
-                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
-                   : NB_FORCE_LOOP_LONG_CLOBBERS);
-#define NB_DIAG_LOOP(TEXT)                                                                                              \
+#define NB_RUN_LOOP(TEXT, CLOBBERS)                                                                                     \
       asm volatile(TEXT                                                                                                  \
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)            \
                    : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk) \
-                   : NB_FORCE_LOOP_CLOBBERS)
-    } else if constexpr (PLACEMENT == 3) {   // TIMING-ONLY diagnostic forms (wrong results): 3 no transcendental,
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V3);
-    } else if constexpr (PLACEMENT == 4) {   // 4 no scalar loads,
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V4);
-    } else if constexpr (PLACEMENT == 5) {   // 5 neither
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V5);
-    } else if constexpr (PLACEMENT == 6) {   // 6..8: what limits full-rate issue (tools/gen_force_loop.py diag_body)
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V6);
+                   : CLOBBERS)
+    if constexpr (LONG) {   // its own kernel: the 64 buffer SGPRs would cost the product loop its 8th resident wave
+      NB_RUN_LOOP(NB_FORCE_LOOP_LONG, NB_FORCE_LOOP_LONG_CLOBBERS);
+    } else if constexpr (PLACEMENT == 0) {   // the product loop one 4-byte placement phase off (kept to re-measure that effect)
+      NB_RUN_LOOP(NB_FORCE_LOOP_V0, NB_FORCE_LOOP_CLOBBERS);
+#ifdef NBODY_DIAG_LOOPS
+    // `make diag` only (libnbody_hip_diag.so): experiment encodings of the same operations (2, 9..13, 16..18: bit-identical)
+    // and TIMING-ONLY forms with WRONG RESULTS (3..8, 14, 15) that price one part of the loop inside the real kernel
+    // (tools/gen_force_loop.py, profiles/r02_loop_diagnostics.md).  The product library does not contain them.
+    } else if constexpr (PLACEMENT == 2) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V2, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 3) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V3, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 4) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V4, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 5) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V5, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 6) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V6, NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 7) {
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V7);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V7, NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 8) {
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V8);
-    } else if constexpr (PLACEMENT == 9) {   // 9..13: CORRECT loops with other encodings of the SGPR-reading instructions
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V9);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V8, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 9) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V9, NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 10) {
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V10);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V10, NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 11) {
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V11);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V11, NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 12) {
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V12);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V12, NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 13) {
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V13);
-    } else if constexpr (PLACEMENT == 16) {   // correct: SGPR operand in src1 (v_subrev)
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V16);
-    } else if constexpr (PLACEMENT == 17) {   // correct: dx, dy in one packed subtraction (11 instructions per pair)
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V17);
-    } else if constexpr (PLACEMENT == 18) {   // correct: eps from a VGPR (the product loop takes it as the literal of v_fmaak_f32)
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V18);
-    } else if constexpr (PLACEMENT == 14) {   // 14, 15: TIMING-ONLY (wrong results): VGPR-sourced coordinates with the transcendental, + an LDS read per source
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V14);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V13, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 14) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V14, NB_FORCE_LOOP_CLOBBERS);
     } else if constexpr (PLACEMENT == 15) {
       __shared__ f4 diag_tile[64];
       if (threadIdx.x < 64) diag_tile[threadIdx.x] = me[0];
       __syncthreads();
-      NB_DIAG_LOOP(NB_FORCE_LOOP_V15);
-#undef NB_DIAG_LOOP
-    } else if constexpr (PLACEMENT == 2) {   // experiment: staggered s_load_dwordx8 delivery
-      asm volatile(NB_FORCE_LOOP_V2
-                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
-                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
-                   : NB_FORCE_LOOP_CLOBBERS);
-    } else if constexpr (PLACEMENT == 1) {
-      asm volatile(NB_FORCE_LOOP_V1
-                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
-                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
-                   : NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V15, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 16) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V16, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 17) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V17, NB_FORCE_LOOP_CLOBBERS);
+    } else if constexpr (PLACEMENT == 18) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V18, NB_FORCE_LOOP_CLOBBERS);
+#endif
     } else {
-      asm volatile(NB_FORCE_LOOP_V0
-                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)
-                   : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk)
-                   : NB_FORCE_LOOP_CLOBBERS);
+      static_assert(PLACEMENT == 1 || LONG, "this loop form exists in the diagnostic build only (make diag)");
+      NB_RUN_LOOP(NB_FORCE_LOOP_V1, NB_FORCE_LOOP_CLOBBERS);
     }
+#undef NB_RUN_LOOP
     j += groups * group;
   }
   asm volatile("" :: "s"(warm0), "s"(warm1));   // the warm-up loads must not be dropped as dead
@@ -591,11 +652,12 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a) {
   s.close(blocked, blocked && (count % a.sum_block) != 0);
   // partial sums in flight (+ the velocity word): as many as keep the kernel's resident waves — 11 (63 VGPRs, 8 waves per
   // SIMD) for the product kernel, 13 (71 VGPRs; its SGPRs allow 7 waves) for the long-buffer kernel of small launches
-  finish_rows<float, f4, 1, LONG ? 13 : 11>(seg, i, row_end, me, s);
+  finish_rows<float, f4, 1, WS, LONG ? 13 : 11>(seg, i, row_end, me, s, ws_sums);
 }
-template <int PLACEMENT>
-__global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) { force_isa_f32_body<PLACEMENT, 0>(a); }
-__global__ void __launch_bounds__(kBlock) force_isa_long_f32(ForceArgs a) { force_isa_f32_body<1, 1>(a); }
+template <int PLACEMENT, int WS>
+__global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<PLACEMENT, 0, WS>(a, ws_sums); }
+template <int WS>
+__global__ void __launch_bounds__(kBlock) force_isa_long_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<1, 1, WS>(a, ws_sums); }
 
 // ---------------------------------------------------------------------------
 // LDS variant (the north_star's "source bodies tiled into LDS", tile = 256 by
@@ -608,11 +670,10 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
   static_assert(TILE % kBlock == 0, "tile is a multiple of the workgroup");
   constexpr int LPT = TILE / kBlock;   // loads per thread per tile
   __shared__ f4 tile[2][TILE];
-  int seg, jb, je, rb;
-  block_segment(a, &seg, &jb, &je, &rb);
+  int seg, jb, je, lane_row;
+  wave_work<R, 1>(a, &seg, &jb, &je, &lane_row);
   const float eps = soft_f32();
   const f4* src = (const f4*)a.src;
-  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[R];
   load_rows<float, f4, R>(a, lane_row, row_end, me);
@@ -664,7 +725,7 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
     buf ^= 1;
   }
   s.close(blocked, blocked && ((je - jb) % a.sum_block) != 0);
-  finish_rows<float, f4, R>(seg, lane_row, row_end, me, s);
+  finish_rows<float, f4, R, 1>(seg, lane_row, row_end, me, s, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -674,12 +735,11 @@ __global__ void __launch_bounds__(kBlock) force_lds_f32(ForceArgs a) {
 // amortised over the R bodies of the lane.
 template <int R, int ARITH>
 __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
-  int seg, jb, je, rb;
-  block_segment(a, &seg, &jb, &je, &rb);
+  int seg, jb, je, lane_row;
+  wave_work<R, 1>(a, &seg, &jb, &je, &lane_row);
   const float eps = soft_f32();
   const f4* src = (const f4*)a.src;
   const int lane = threadIdx.x & 63;
-  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[R];
   load_rows<float, f4, R>(a, lane_row, row_end, me);
@@ -717,7 +777,7 @@ __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
     }
   }
   s.close(blocked, blocked && ((je - jb) % a.sum_block) != 0);
-  finish_rows<float, f4, R>(seg, lane_row, row_end, me, s);
+  finish_rows<float, f4, R, 1>(seg, lane_row, row_end, me, s, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -728,10 +788,9 @@ __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
 // lane; 48 accumulators live in VGPRs.  A study mode, not the timed path.
 template <int ARITH>
 __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
-  int seg, jb, je, rb;
-  block_segment(a, &seg, &jb, &je, &rb);
+  int seg, jb, je, i;
+  wave_work<1, 1>(a, &seg, &jb, &je, &i);
   const float eps = soft_f32();
-  const int i = a.row0 + rb * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   f4 me[1];
   load_rows<float, f4, 1>(a, i, row_end, me);
@@ -772,18 +831,18 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
   Sums<float, 1> s;
   s.clear();
   s.bx[0] = tree16(rx); s.by[0] = tree16(ry); s.bz[0] = tree16(rz);
-  finish_rows<float, f4, 1>(seg, i, row_end, me, s);
+  finish_rows<float, f4, 1, 1>(seg, i, row_end, me, s, nullptr);
 }
 
 // ---------------------------------------------------------------------------
 // fp64 (BASELINE config 5).  SMEM delivery, R bodies per lane.  One sequential sum per segment (fp64 has 29 more
 // bits than the 1e-5 target needs; sum_block is ignored).
-template <int R>
+template <int R, int WS>
 __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
-  int seg, jb, je, rb;
-  block_segment(a, &seg, &jb, &je, &rb);
+  NB_WS_LDS(d4, WS);
+  int seg, jb, je, lane_row;
+  wave_work<R, WS>(a, &seg, &jb, &je, &lane_row);
   const double eps = (double)soft_f32();
-  const int lane_row = a.row0 + rb * (kBlock * R) + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   d4 me[R];
   load_rows<double, d4, R>(a, lane_row, row_end, me);
@@ -808,18 +867,18 @@ __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
     for (int r = 0; r < R; ++r) pair_f64(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
   }
   s.close(false, false);
-  finish_rows<double, d4, R>(seg, lane_row, row_end, me, s);
+  finish_rows<double, d4, R, WS>(seg, lane_row, row_end, me, s, ws_sums);
 }
 
 // ---------------------------------------------------------------------------
 // fp64 with the hand-scheduled loop (force_loop_gfx950.inc, NB_FORCE_LOOP_F64_*): one body per lane, 4 sources
 // per iteration, every instruction 8 bytes (v_rsq_f64 in its _e64 encoding).  Same bits as force_smem_f64<1>.
-template <int PLACEMENT>
+template <int PLACEMENT, int WS>
 __global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
-  int seg, jb, je, rb;
-  block_segment(a, &seg, &jb, &je, &rb);
+  NB_WS_LDS(d4, WS);
+  int seg, jb, je, i;
+  wave_work<1, WS>(a, &seg, &jb, &je, &i);
   const double eps = (double)soft_f32();
-  const int i = a.row0 + rb * kBlock + threadIdx.x;
   const int row_end = a.row0 + a.row_count;
   d4 me[1];
   load_rows<double, d4, 1>(a, i, row_end, me);
@@ -855,7 +914,7 @@ __global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
   Sums<double, 1> s;
   s.clear();
   s.bx[0] = ax; s.by[0] = ay; s.bz[0] = az;
-  finish_rows<double, d4, 1>(seg, i, row_end, me, s);
+  finish_rows<double, d4, 1, WS>(seg, i, row_end, me, s, ws_sums);
 }
 
 // ---------------------------------------------------------------------------
@@ -875,7 +934,7 @@ __global__ void __launch_bounds__(kBlock) combine_kernel(ForceArgs a) {
     V4 p[C];
 #pragma unroll
     for (int k = 0; k < C; ++k)
-      if (sg0 + k < a.nseg) p[k] = part[(size_t)(sg0 + k) * a.n_rows + i];
+      if (sg0 + k < a.nseg) p[k] = part[(size_t)(sg0 + k) * a.part_stride + (i - a.row0)];
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       if (sg0 + k < a.nseg) {

@@ -47,7 +47,9 @@ class NBody:
         return dict(variant=names.get(self.info(L.INFO_VARIANT), "?"), iblock=self.info(L.INFO_IBLOCK),
                     jsub=self.info(L.INFO_JSUB), nseg=self.info(L.INFO_NSEG), tile=self.info(L.INFO_TILE),
                     sum_order=sums.get(self.info(L.INFO_SUM_ORDER), "?"), sum_block=self.info(L.INFO_SUM_BLOCK),
-                    launches_per_step=self.info(L.INFO_LAUNCHES_PER_STEP),
+                    launches_per_step=self.info(L.INFO_LAUNCHES_PER_STEP), wsplit=self.info(L.INFO_WSPLIT),
+                    isa_phase=self.info(L.INFO_ISA_PHASE), long_buffers=self.info(L.INFO_LONG_BUFFERS),
+                    xcd_map=self.info(L.INFO_XCD_MAP), fuse=self.info(L.INFO_FUSE_COMBINE),
                     n_local=self.info(L.INFO_N_LOCAL), first_body=self.info(L.INFO_FIRST_BODY),
                     rank=self.info(L.INFO_RANK), nranks=self.info(L.INFO_NRANKS))
 
@@ -132,6 +134,25 @@ class NBody:
         L.check(self.lib.nbody_comm_selftest(C.byref(moved)))
         return moved.value
 
+    def comm_selftest_virtual(self, vranks, form):
+        """The transfer plans of `vranks` virtual ranks run through real ncclSend/ncclRecv on a one-rank communicator."""
+        moved = C.c_longlong()
+        L.check(self.lib.nbody_comm_selftest_virtual(int(vranks), int(form), C.byref(moved)))
+        return moved.value
+
+    def comm_probe(self, nbytes, when):
+        """(ms of one RCCL ring step of nbytes from enqueue to done, ms of the force pass beside it); when = 0 alone,
+        1 enqueued just before a full force pass, 2 just after it."""
+        c, f = C.c_double(), C.c_double()
+        L.check(self.lib.nbody_comm_probe(int(nbytes), int(when), C.byref(c), C.byref(f)))
+        return c.value, f.value
+
+    def comm_time(self, reset=False):
+        """(ms the compute stream waited for arriving slices, number of waits) since the last reset (OPT_TIMING = 1)."""
+        ms, cnt = C.c_double(), C.c_longlong()
+        L.check(self.lib.nbody_comm_time(C.byref(ms), C.byref(cnt), int(reset)))
+        return ms.value, cnt.value
+
     @property
     def order(self):
         """The summation order of the current configuration as keyword arguments of the oracle's order()
@@ -139,7 +160,7 @@ class NBody:
         cfg = self.config
         nsl = cfg["nseg"] // cfg["jsub"]
         return dict(nslices=nsl, sub=cfg["jsub"], block=cfg["sum_block"] or 1024,
-                    summ={"seq": 0, "fpga16": 1, "blocked": 2}[cfg["sum_order"]])
+                    summ={"seq": 0, "fpga16": 1, "blocked": 2}[cfg["sum_order"]], wsplit=cfg["wsplit"])
 
     def kernel_time(self, reset=False):
         ms, cnt = C.c_double(), C.c_longlong()
@@ -174,6 +195,17 @@ class NBody:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def comm_plan(form, rank, nranks, n):
+    """The transfer plan of one rank as a list of dicts (pure host arithmetic in the library: no GPU needed)."""
+    lib = L.load()
+    cnt = C.c_int()
+    L.check(lib.nbody_comm_plan(int(form), int(rank), int(nranks), int(n), None, 0, C.byref(cnt)))
+    buf = (C.c_longlong * (7 * max(1, cnt.value)))()
+    L.check(lib.nbody_comm_plan(int(form), int(rank), int(nranks), int(n), buf, cnt.value, C.byref(cnt)))
+    keys = ("group", "send_peer", "send_first", "send_count", "recv_peer", "recv_first", "recv_count")
+    return [dict(zip(keys, buf[7 * k:7 * k + 7])) for k in range(cnt.value)]
 
 
 def unique_id():

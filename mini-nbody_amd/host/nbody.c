@@ -7,7 +7,7 @@
  * §2: billion pair-interactions/s = N^2 * timed_steps / seconds / 1e9.
  *
  * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]
- *              [--sum seq|blocked] [--block K] [--one-launch | --two-launch] [--long-buffers 0|1] [--overlap 0|1|2]
+ *              [--sum seq|blocked] [--block K] [--one-launch | --two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -27,7 +27,7 @@ static double now_s(void) {
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s failed: %s\n", #call, nbody_error_string(rc_)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0, sum = -1, block = 0, two_launch = -1, long_buffers = -1, overlap = -1;
+  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0, sum = -1, block = 0, two_launch = -1, long_buffers = -1, overlap = -1, wsplit = 0;
   unsigned long long seed = NBODY_IC_DEFAULT_SEED;
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
@@ -41,11 +41,12 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--one-launch")) two_launch = 0;
     else if (!strcmp(argv[a], "--overlap") && a + 1 < argc) overlap = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--long-buffers") && a + 1 < argc) long_buffers = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--wsplit") && a + 1 < argc) wsplit = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--sum") && a + 1 < argc) { ++a; sum = !strcmp(argv[a], "seq") ? NBODY_SUM_SEQ : NBODY_SUM_BLOCKED; }
     else if (!strcmp(argv[a], "--block") && a + 1 < argc) block = atoi(argv[++a]);
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1] [--overlap 0|1|2]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   const float dt = 0.01f;
@@ -57,6 +58,7 @@ int main(int argc, char **argv) {
   if (block > 0) CHECK(nbody_set_option(NBODY_OPT_SUM_BLOCK, block));
   if (two_launch >= 0) CHECK(nbody_set_option(NBODY_OPT_FUSE_COMBINE, !two_launch));   /* in-launch combine or separate kernel (same bits) */
   if (long_buffers >= 0) CHECK(nbody_set_option(NBODY_OPT_ISA_LONG_BUFFERS, long_buffers));
+  if (wsplit > 0) CHECK(nbody_set_option(NBODY_OPT_WSPLIT, wsplit));              /* waves of a workgroup share rows and split the segment (4) or not (1) */
   if (overlap >= 0) CHECK(nbody_set_option(NBODY_OPT_OVERLAP, overlap));        /* multi-GPU: 0 gather first, 1 own slice then the rest, 2 per arriving slice */
 
   double total = 0.0;
@@ -116,13 +118,14 @@ int main(int argc, char **argv) {
     free(buf);
   }
   double avg = total / (double)(iters - 1);
-  long long info_r = 0, info_s = 0, info_b = 0, info_l = 0;
+  long long info_r = 0, info_s = 0, info_b = 0, info_l = 0, info_w = 0;
+  nbody_get_info(NBODY_INFO_WSPLIT, &info_w);
   nbody_get_info(NBODY_INFO_IBLOCK, &info_r);
   nbody_get_info(NBODY_INFO_NSEG, &info_s);
   nbody_get_info(NBODY_INFO_SUM_BLOCK, &info_b);
   nbody_get_info(NBODY_INFO_LAUNCHES_PER_STEP, &info_l);
-  printf("%d Bodies (%s, %d GPU%s, %s loop, %lld bodies/lane, %lld segments, sum block %lld, %lld launch%s/step): average %0.3f Billion Interactions / second (%.3f ms / step)\n",
-         n, fp64 ? "fp64" : "fp32", gpus, gpus > 1 ? "s" : "", host_loop ? "host" : "device", info_r, info_s, info_b, info_l,
+  printf("%d Bodies (%s, %d GPU%s, %s loop, %lld bodies/lane, %lld segments x %lld pieces, sum block %lld, %lld launch%s/step): average %0.3f Billion Interactions / second (%.3f ms / step)\n",
+         n, fp64 ? "fp64" : "fp32", gpus, gpus > 1 ? "s" : "", host_loop ? "host" : "device", info_r, info_s, info_w, info_b, info_l,
          info_l > 1 ? "es" : "", 1e-9 * (double)n * (double)n / avg, 1e3 * avg);
   nbody_shutdown();
   return 0;

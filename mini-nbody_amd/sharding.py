@@ -28,6 +28,13 @@ def segment_bounds(q, t, n, nslices, sub):
     return b, e
 
 
+def piece_bounds(jb, je, w, wsplit):
+    """Piece w of `wsplit` of the segment [jb, je): what wave w of a workgroup walks (NBODY_OPT_WSPLIT = 4)."""
+    piece = (je - jb + wsplit - 1) // wsplit
+    b = min(jb + w * piece, je)
+    return b, min(b + piece, je)
+
+
 def ring_slice(rank, s, nranks):
     """Slice that reaches `rank` at ring step s (s = 0: its own)."""
     return (rank - s) % nranks

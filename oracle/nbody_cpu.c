@@ -5,9 +5,10 @@
  * program mini-nbody_amd/host/nbody.c — which makes the two directly comparable (same checksum in --strict mode).
  *
  * Summation order: --sum seq (default: what a plain CPU nbody.c does, one accumulator per body) or
- * --sum blocked [--block K] [--segments S]: the GPU engine's order (blocks of K sources, S source segments).
+ * --sum blocked [--block K] [--segments S] [--wsplit W]: the GPU engine's order (blocks of K sources, S source segments
+ * of W pieces each).
  *
- * usage: nbody_cpu [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T] [--sum seq|blocked] [--block K] [--segments S]
+ * usage: nbody_cpu [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T] [--sum seq|blocked] [--block K] [--segments S] [--wsplit W]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -24,7 +25,7 @@ static double now_s(void) {
 }
 
 int main(int argc, char **argv) {
-  int n = 4096, iters = 10, fp64 = 0, npos = 0, rsq = REF_RSQRT_F64, threads = 0, sum = REF_SUM_SEQ, block = 1024, segments = 1;
+  int n = 4096, iters = 10, fp64 = 0, npos = 0, rsq = REF_RSQRT_F64, threads = 0, sum = REF_SUM_SEQ, block = 1024, segments = 1, wsplit = 1;
   unsigned long long seed = 42ull;
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--fp64")) fp64 = 1;
@@ -34,9 +35,10 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--sum") && a + 1 < argc) { ++a; sum = !strcmp(argv[a], "blocked") ? REF_SUM_BLOCKED : REF_SUM_SEQ; }
     else if (!strcmp(argv[a], "--block") && a + 1 < argc) block = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--segments") && a + 1 < argc) segments = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--wsplit") && a + 1 < argc) wsplit = atoi(argv[++a]);
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T] [--sum seq|blocked] [--block K] [--segments S]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T] [--sum seq|blocked] [--block K] [--segments S] [--wsplit W]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   if (threads <= 0) {   /* small problems: do not wake more threads than there are 256-body chunks of rows */
@@ -49,7 +51,7 @@ int main(int argc, char **argv) {
   if (!fp64) {
     float *pos = (float *)malloc(sizeof(float) * 4 * (size_t)n), *vel = (float *)malloc(sizeof(float) * 4 * (size_t)n);
     ref_ic_f32(pos, vel, n, 0, n, seed);
-    const ref_order_t order = {REF_D2_FMA3, rsq, sum, block, 1, segments > 0 ? segments : 1};
+    const ref_order_t order = {REF_D2_FMA3, rsq, sum, block, 1, segments > 0 ? segments : 1, wsplit > 0 ? wsplit : 1};
     for (int it = 1; it <= iters; ++it) {
       double t0 = now_s();
       ref_step_f32_order(pos, vel, dt, n, 1, &order);   /* bodyForce (kick) + integrate (drift) */

@@ -191,7 +191,7 @@ void ref_forces_f32(const float *rows, int n_rows, const float *src, int n_src, 
   if (n_rows <= 0) return;
   if (sum_mode == REF_SUM_FPGA16) { fpga16_f32(rows, n_rows, src, n_src, acc, d2_mode, rsqrt_mode); return; }
   if (sum_mode == REF_SUM_BLOCKED) {   /* one segment, blocks of 1024 (the engine's default block) */
-    ref_order_t o = {d2_mode, rsqrt_mode, REF_SUM_BLOCKED, 1024, 1, 1};
+    ref_order_t o = {d2_mode, rsqrt_mode, REF_SUM_BLOCKED, 1024, 1, 1, 1};
     ref_forces_f32_order(rows, n_rows, src, n_src, acc, &o);
     return;
   }
@@ -223,13 +223,26 @@ void ref_segment_bounds(int q, int t, int n, int nslices, int sub, int *jb, int 
   *jb = b; *je = e;
 }
 
-/* Per row: for every segment in ascending order { level 1: a = 0, a = fma(d, inv3, a) over a block of sources
- * (S/fxyz.vhd:120-127); level 2: b = b + a per finished block }, then F = p_0, F = F + p_s.  In REF_SUM_SEQ a segment is
- * one block and its sum is `a` itself (no addition of zero).  Rows are processed LANES at a time for the vectoriser;
- * the order of operations per row is exactly the one written here. */
+/* piece w of `ws` of the segment [jb, je): ceil(len / ws) sources each, the last ones shorter or empty */
+void ref_piece_bounds(int jb, int je, int w, int ws, int *pb, int *pe) {
+  int piece = (je - jb + ws - 1) / ws;
+  int b = jb + w * piece;
+  int e = b + piece;
+  if (b > je) b = je;
+  if (e > je) e = je;
+  *pb = b; *pe = e;
+}
+
+/* Per row: for every segment in ascending order { for every piece w of the segment's `wsplit` (1 or 4: the four waves of a
+ * workgroup, mini-nbody_amd/csrc/nbody_kernels.hpp piece_bounds()) in ascending order { level 1: a = 0, a = fma(d, inv3, a)
+ * over a block of sources counted from the piece's first (S/fxyz.vhd:120-127); level 2: b = b + a per finished block };
+ * level 3: the segment's sum = ((b_0 + b_1) + b_2) + b_3 — the reference's own remedy, partial sums joined by an adder
+ * (S/fxyz.vhd:129-145, S/final_adder.vhd:88-104), in the shape a SIMT workgroup has }, then F = p_0, F = F + p_s.
+ * In REF_SUM_SEQ a piece is one block and its sum is `a` itself (no addition of zero); an empty piece contributes +0.
+ * Rows are processed LANES at a time for the vectoriser; the order of operations per row is exactly the one written here. */
 #define DEFINE_ORDER_KERNEL(NAME, D2MODE, RSQMODE)                                                       \
   static void NAME(const float *rows, int n_rows, const float *src, int n_src, float *acc,               \
-                   int blocked, int block, int nslices, int sub) {                                       \
+                   int blocked, int block, int nslices, int sub, int wsplit) {                           \
     const float soft = bits_to_float(REF_SOFT_BITS);                                                     \
     const int nblk = (n_rows + LANES - 1) / LANES;                                                       \
     _Pragma("omp parallel for schedule(dynamic, 4)")                                                     \
@@ -241,31 +254,39 @@ void ref_segment_bounds(int q, int t, int n, int nslices, int sub, int *jb, int 
         tx[l] = ty[l] = tz[l] = 0.0f;                                                                    \
       }                                                                                                  \
       for (int seg = 0; seg < nslices * sub; ++seg) {                                                    \
-        int jb, je;                                                                                      \
-        ref_segment_bounds(seg / sub, seg % sub, n_src, nslices, sub, &jb, &je);                         \
-        float px[LANES], py[LANES], pz[LANES];                                                           \
-        for (int l = 0; l < LANES; ++l) px[l] = py[l] = pz[l] = 0.0f;                                    \
-        const int step = blocked ? block : (je - jb > 0 ? je - jb : 1);                                  \
-        for (int j0 = jb; j0 < je; j0 += step) {                                                         \
-          const int j1 = j0 + step < je ? j0 + step : je;                                                \
-          float fx[LANES], fy[LANES], fz[LANES];                                                         \
-          for (int l = 0; l < LANES; ++l) fx[l] = fy[l] = fz[l] = 0.0f;                                  \
-          for (int j = j0; j < j1; ++j) {                                                                \
-            const float xt = src[4 * j], yt = src[4 * j + 1], zt = src[4 * j + 2];                       \
-            _Pragma("omp simd")                                                                          \
-            for (int l = 0; l < LANES; ++l) {                                                            \
-              const float xi = xs[l], yi = ys[l], zi = zs[l];                                            \
-              PAIR_F32(D2MODE, RSQMODE)                                                                  \
-              fx[l] = fmaf(dx, inv3, fx[l]);                                                             \
-              fy[l] = fmaf(dy, inv3, fy[l]);                                                             \
-              fz[l] = fmaf(dz, inv3, fz[l]);                                                             \
+        int sb, se;                                                                                      \
+        ref_segment_bounds(seg / sub, seg % sub, n_src, nslices, sub, &sb, &se);                         \
+        float gx[LANES], gy[LANES], gz[LANES];                                                           \
+        for (int l = 0; l < LANES; ++l) gx[l] = gy[l] = gz[l] = 0.0f;                                    \
+        for (int w = 0; w < wsplit; ++w) {                                                               \
+          int jb, je;                                                                                    \
+          ref_piece_bounds(sb, se, w, wsplit, &jb, &je);                                                 \
+          float px[LANES], py[LANES], pz[LANES];                                                         \
+          for (int l = 0; l < LANES; ++l) px[l] = py[l] = pz[l] = 0.0f;                                  \
+          const int step = blocked ? block : (je - jb > 0 ? je - jb : 1);                                \
+          for (int j0 = jb; j0 < je; j0 += step) {                                                       \
+            const int j1 = j0 + step < je ? j0 + step : je;                                              \
+            float fx[LANES], fy[LANES], fz[LANES];                                                       \
+            for (int l = 0; l < LANES; ++l) fx[l] = fy[l] = fz[l] = 0.0f;                                \
+            for (int j = j0; j < j1; ++j) {                                                              \
+              const float xt = src[4 * j], yt = src[4 * j + 1], zt = src[4 * j + 2];                     \
+              _Pragma("omp simd")                                                                        \
+              for (int l = 0; l < LANES; ++l) {                                                          \
+                const float xi = xs[l], yi = ys[l], zi = zs[l];                                          \
+                PAIR_F32(D2MODE, RSQMODE)                                                                \
+                fx[l] = fmaf(dx, inv3, fx[l]);                                                           \
+                fy[l] = fmaf(dy, inv3, fy[l]);                                                           \
+                fz[l] = fmaf(dz, inv3, fz[l]);                                                           \
+              }                                                                                          \
             }                                                                                            \
+            if (blocked) { for (int l = 0; l < LANES; ++l) { px[l] = px[l] + fx[l]; py[l] = py[l] + fy[l]; pz[l] = pz[l] + fz[l]; } } \
+            else { for (int l = 0; l < LANES; ++l) { px[l] = fx[l]; py[l] = fy[l]; pz[l] = fz[l]; } }    \
           }                                                                                              \
-          if (blocked) { for (int l = 0; l < LANES; ++l) { px[l] = px[l] + fx[l]; py[l] = py[l] + fy[l]; pz[l] = pz[l] + fz[l]; } } \
-          else { for (int l = 0; l < LANES; ++l) { px[l] = fx[l]; py[l] = fy[l]; pz[l] = fz[l]; } }      \
+          if (w == 0) { for (int l = 0; l < LANES; ++l) { gx[l] = px[l]; gy[l] = py[l]; gz[l] = pz[l]; } } \
+          else { for (int l = 0; l < LANES; ++l) { gx[l] = gx[l] + px[l]; gy[l] = gy[l] + py[l]; gz[l] = gz[l] + pz[l]; } } \
         }                                                                                                \
-        if (seg == 0) { for (int l = 0; l < LANES; ++l) { tx[l] = px[l]; ty[l] = py[l]; tz[l] = pz[l]; } } \
-        else { for (int l = 0; l < LANES; ++l) { tx[l] = tx[l] + px[l]; ty[l] = ty[l] + py[l]; tz[l] = tz[l] + pz[l]; } } \
+        if (seg == 0) { for (int l = 0; l < LANES; ++l) { tx[l] = gx[l]; ty[l] = gy[l]; tz[l] = gz[l]; } } \
+        else { for (int l = 0; l < LANES; ++l) { tx[l] = tx[l] + gx[l]; ty[l] = ty[l] + gy[l]; tz[l] = tz[l] + gz[l]; } } \
       }                                                                                                  \
       for (int l = 0; l < LANES; ++l) {                                                                  \
         int i = b * LANES + l; if (i >= n_rows) break;                                                   \
@@ -283,13 +304,13 @@ void ref_forces_f32_order(const float *rows, int n_rows, const float *src, int n
   if (n_rows <= 0) return;
   const int blocked = o->sum_mode == REF_SUM_BLOCKED;
   const int block = o->block > 0 ? o->block : 1024;
-  const int nsl = o->nslices > 0 ? o->nslices : 1, sub = o->sub > 0 ? o->sub : 1;
+  const int nsl = o->nslices > 0 ? o->nslices : 1, sub = o->sub > 0 ? o->sub : 1, ws = o->wsplit > 0 ? o->wsplit : 1;
   if (o->d2_mode == REF_D2_REFERENCE) {
-    if (o->rsqrt_mode == REF_RSQRT_DIVSQRT) ord_ref_div(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
-    else ord_ref_f64(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
+    if (o->rsqrt_mode == REF_RSQRT_DIVSQRT) ord_ref_div(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub, ws);
+    else ord_ref_f64(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub, ws);
   } else {
-    if (o->rsqrt_mode == REF_RSQRT_DIVSQRT) ord_fma_div(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
-    else ord_fma_f64(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub);
+    if (o->rsqrt_mode == REF_RSQRT_DIVSQRT) ord_fma_div(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub, ws);
+    else ord_fma_f64(rows, n_rows, src, n_src, acc, blocked, block, nsl, sub, ws);
   }
 }
 

@@ -54,12 +54,14 @@ enum { REF_SUM_SEQ = 0,      /* one accumulator, sources in ascending order (S/t
 /* The engine's full summation order (mini-nbody_amd/csrc/nbody_kernels.hpp): the sources are cut into `nslices` balanced
  * slices (one per rank) of `sub` pieces each; every segment is summed on its own from zero (sum_mode, `block` sources per
  * block when sum_mode == REF_SUM_BLOCKED, counted from the segment's first source), and the segment sums are added in
- * ascending source order: F = ((p_0 + p_1) + p_2) + ...  nslices = sub = 1 and REF_SUM_SEQ is the plain sequential sum. */
+ * ascending source order: F = ((p_0 + p_1) + p_2) + ...  nslices = sub = wsplit = 1 and REF_SUM_SEQ is the plain sequential sum. */
 typedef struct {
   int d2_mode, rsqrt_mode;
   int sum_mode;      /* REF_SUM_SEQ or REF_SUM_BLOCKED */
   int block;         /* sources per block (REF_SUM_BLOCKED) */
   int nslices, sub;  /* segmentation of the sources */
+  int wsplit;        /* pieces per segment (1, or 4 = the four waves of a workgroup, NBODY_OPT_WSPLIT): each piece is summed on
+                        its own as above and the piece sums are added in ascending order to give the segment's sum; 0 = 1 */
 } ref_order_t;
 
 /* ---- pipeline stages, one function per reference entity ---- */
@@ -89,6 +91,8 @@ void ref_forces_f32(const float *rows, int n_rows, const float *src, int n_src, 
                     int d2_mode, int rsqrt_mode, int sum_mode);
 /* forces in the engine's order (segments, blocks): rows vs ALL n_src sources */
 void ref_forces_f32_order(const float *rows, int n_rows, const float *src, int n_src, float *acc, const ref_order_t *order);
+/* piece w of ws of a segment */
+void ref_piece_bounds(int jb, int je, int w, int ws, int *pb, int *pe);
 /* segment (q, t) of the order: [*jb, *je) */
 void ref_segment_bounds(int q, int t, int n, int nslices, int sub, int *jb, int *je);
 /* fp64 arithmetic on fp64 inputs (the fp64 config's oracle) */

@@ -24,11 +24,11 @@ _fp = C.POINTER(C.c_float)
 class Order(C.Structure):
     """ref_order_t: the engine's summation order (segments of the sources, blocks inside a segment)."""
     _fields_ = [("d2_mode", C.c_int), ("rsqrt_mode", C.c_int), ("sum_mode", C.c_int), ("block", C.c_int),
-                ("nslices", C.c_int), ("sub", C.c_int)]
+                ("nslices", C.c_int), ("sub", C.c_int), ("wsplit", C.c_int)]
 
 
-def order(d2=D2_FMA3, rsqrt=RSQRT_F64, summ=SUM_BLOCKED, block=DEFAULT_BLOCK, nslices=1, sub=1):
-    return Order(d2, rsqrt, summ, block, nslices, sub)
+def order(d2=D2_FMA3, rsqrt=RSQRT_F64, summ=SUM_BLOCKED, block=DEFAULT_BLOCK, nslices=1, sub=1, wsplit=1):
+    return Order(d2, rsqrt, summ, block, nslices, sub, wsplit)
 
 
 def build(force=False):

@@ -10,7 +10,9 @@ every operation evaluated exactly with fractions.Fraction and rounded once to bi
 the fma-contracted form the timed kernels use; 1/sqrt rounded once from a binary64 evaluation).
 Summation order: nslices x sub segments of the sources (balanced slices, ceil pieces), blocks of `block` sources summed
 from zero and added in ascending order (block = 0: one sequential sum per segment), segments added in ascending
-order — include/nbody.h NBODY_SUM_BLOCKED / oracle/nbody_ref.h ref_order_t.
+order — include/nbody.h NBODY_SUM_BLOCKED / oracle/nbody_ref.h ref_order_t.  With wsplit = 4 (NBODY_OPT_WSPLIT, the four
+waves of a workgroup) a segment is first cut into 4 pieces of ceil(len / 4) sources, each summed as above on its own, and
+the piece sums are added in ascending order to give the segment's sum (a third level).
 
 Inputs are generated here with the repository's seeded generator formula restated (SplitMix64 -> uniform [-1, 1)),
 and are stored in the fixture as hex words, so consumers need nothing but the JSON.
@@ -104,33 +106,45 @@ def segments(n, nslices, sub):
     return out
 
 
-def forces(pos, nslices, sub, block):
+def pieces(sb, se, wsplit):
+    piece = (se - sb + wsplit - 1) // wsplit
+    out = []
+    for w in range(wsplit):
+        b = min(sb + w * piece, se)
+        out.append((b, min(b + piece, se)))
+    return out
+
+
+def forces(pos, nslices, sub, block, wsplit=1):
     soft = bits_f32(SOFT_BITS)
     n = len(pos)
     out = []
     for i in range(n):
         xi, yi, zi = pos[i][0], pos[i][1], pos[i][2]
         total = None
-        for (jb, je) in segments(n, nslices, sub):
-            seg = [0.0, 0.0, 0.0]
-            step = block if block > 0 else max(1, je - jb)
-            blocked = block > 0
-            for j0 in range(jb, je, step):
-                a = [0.0, 0.0, 0.0]
-                for j in range(j0, min(j0 + step, je)):
-                    dx, dy, dz = add(pos[j][0], -xi), add(pos[j][1], -yi), add(pos[j][2], -zi)
-                    d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, soft)))
-                    inv = rsqrt(d2)
-                    inv3 = mul(inv, mul(inv, inv))
-                    a = [fma(dx, inv3, a[0]), fma(dy, inv3, a[1]), fma(dz, inv3, a[2])]
-                seg = [add(s, x) for s, x in zip(seg, a)] if blocked else a
+        for (sb, se) in segments(n, nslices, sub):
+            seg = None
+            for (jb, je) in pieces(sb, se, wsplit):
+                pc = [0.0, 0.0, 0.0]
+                step = block if block > 0 else max(1, je - jb)
+                blocked = block > 0
+                for j0 in range(jb, je, step):
+                    a = [0.0, 0.0, 0.0]
+                    for j in range(j0, min(j0 + step, je)):
+                        dx, dy, dz = add(pos[j][0], -xi), add(pos[j][1], -yi), add(pos[j][2], -zi)
+                        d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, soft)))
+                        inv = rsqrt(d2)
+                        inv3 = mul(inv, mul(inv, inv))
+                        a = [fma(dx, inv3, a[0]), fma(dy, inv3, a[1]), fma(dz, inv3, a[2])]
+                    pc = [add(s, x) for s, x in zip(pc, a)] if blocked else a
+                seg = pc if seg is None else [add(s, x) for s, x in zip(seg, pc)]
             total = seg if total is None else [add(t, s) for t, s in zip(total, seg)]
         out.append(total + [0.0])
     return out
 
 
-def step(pos, vel, dt, nslices, sub, block):
-    f = forces(pos, nslices, sub, block)
+def step(pos, vel, dt, nslices, sub, block, wsplit=1):
+    f = forces(pos, nslices, sub, block, wsplit)
     vel = [[fma(dt, f[i][c], vel[i][c]) for c in range(3)] + [vel[i][3]] for i in range(len(pos))]
     pos = [[fma(vel[i][c], dt, pos[i][c]) for c in range(3)] + [pos[i][3]] for i in range(len(pos))]
     return pos, vel, f
@@ -140,16 +154,16 @@ def hexwords(rows):
     return ["%08x" % f32_bits(v) for row in rows for v in row]
 
 
-def make(name, n, seed, steps, nslices, sub, block):
+def make(name, n, seed, steps, nslices, sub, block, wsplit=1):
     pos, vel = uniform_words(n, seed)
     dt = bits_f32(f32_bits(0.01))
     fx = {"n": n, "seed": seed, "steps": steps, "dt_bits": "%08x" % f32_bits(dt),
-          "order": {"nslices": nslices, "sub": sub, "block": block, "summ": "blocked" if block > 0 else "seq"},
+          "order": {"nslices": nslices, "sub": sub, "block": block, "summ": "blocked" if block > 0 else "seq", "wsplit": wsplit},
           "arith": "d2 = fma(dx,dx,fma(dy,dy,fma(dz,dz,eps))), inv = (float)(1.0/sqrt((double)d2)), inv3 = inv*(inv*inv), F = fma(d, inv3, F)",
           "pos0": hexwords(pos), "vel0": hexwords(vel)}
     p, v = pos, vel
     for s in range(steps):
-        p, v, f = step(p, v, dt, nslices, sub, block)
+        p, v, f = step(p, v, dt, nslices, sub, block, wsplit)
         if s == 0:
             fx["forces0"] = hexwords(f)
     fx["pos"] = hexwords(p)
@@ -159,6 +173,13 @@ def make(name, n, seed, steps, nslices, sub, block):
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "wsplit":   # only the fixtures of the wave-split order (the others are unchanged)
+        make("system_n560_wsplit4.json", 560, 5, 2, 1, 2, 64, wsplit=4)   # 2 segments of 280 = 4 pieces of 70: a block fold + 6 in each
+        make("system_n90_wsplit4_sharded.json", 90, 3, 3, 3, 2, 64, wsplit=4)  # 3 rank slices x 2 segments of 15 = pieces of 4,4,4,3
+        sys.exit(0)
     make("system_n64_seq.json", 64, 42, 10, 1, 1, 0)           # the plain sequential sum, 10 steps (BASELINE config 1's loop, tiny)
     make("system_n200_blocked.json", 200, 7, 3, 1, 3, 64)      # 3 segments of 67/67/66 sources, blocks of 64 + a remainder
     make("system_n150_sharded.json", 150, 9, 2, 4, 2, 64)      # 4 rank slices (38/38/37/37) x 2 pieces: the multi-GPU order
+    make("system_n560_wsplit4.json", 560, 5, 2, 1, 2, 64, wsplit=4)
+    make("system_n90_wsplit4_sharded.json", 90, 3, 3, 3, 2, 64, wsplit=4)

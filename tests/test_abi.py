@@ -59,3 +59,10 @@ def test_option_validation_needs_no_gpu(nb):
     assert lib.nbody_set_option(nb.OPT_VARIANT, 9) == nb._lib.ERR_ARG
     assert lib.nbody_set_option(999, 0) == nb._lib.ERR_ARG
     assert lib.nbody_set_option(nb.OPT_IBLOCK, 0) == 0
+    assert lib.nbody_set_option(nb.OPT_WSPLIT, 2) == nb._lib.ERR_ARG
+    assert lib.nbody_set_option(nb.OPT_WSPLIT, -1) == 0
+    # loop forms of the diagnostic build (experiment encodings, timing-only forms with wrong results) are refused
+    for phase in list(range(2, 19)):
+        assert lib.nbody_set_option(nb.OPT_ISA_PHASE, phase) == nb._lib.ERR_UNSUPPORTED, phase
+    assert lib.nbody_set_option(nb.OPT_ISA_PHASE, 19) == nb._lib.ERR_ARG
+    assert lib.nbody_set_option(nb.OPT_ISA_PHASE, 1) == 0

@@ -1,0 +1,109 @@
+"""bench.py's supervision of its worker processes (`python bench.py --gpus N` without torch.distributed.run, and one
+supervisor per rank under it), with a stub in place of the GPU worker: environment handed to the workers, a failing
+worker -> one retry on the host transport with the reason recorded, a hang -> killed at the deadline and retried, and
+the supervisors of a torch.distributed.run job agreeing through their shared directory.  No GPU, no torch."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import threading
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+STUB = textwrap.dedent('''
+    import json, os, sys, time
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    transport = sys.argv[sys.argv.index("--transport") + 1]
+    mode = os.environ.get("STUB_MODE", "ok")
+    assert os.environ["NBODY_BENCH_WORKER"] == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    assert "TORCHELASTIC_USE_AGENT_STORE" not in os.environ and "OMP_NUM_THREADS" not in os.environ
+    if transport != "host":
+        if mode == "fail" and rank == world - 1:
+            sys.stderr.write("RCCL error 5 near nbody_hip.hip:123\\n")
+            sys.exit(3)
+        if mode == "hang" and rank == 0:
+            time.sleep(3600)
+        if mode == "hang":
+            time.sleep(3600)      # the others wait for rank 0 in a collective
+    if rank == 0:
+        print("noise before the line")
+        print(json.dumps({"metric": "stub", "n_gpus": world, "config": {"comm": "allgather / %s / overlap 1" % ("host-staged" if transport == "host" else "rccl")},
+                          "env": {k: os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}, "argv": sys.argv[1:]}))
+''')
+
+
+@pytest.fixture()
+def stub(tmp_path):
+    p = tmp_path / "stub_worker.py"
+    p.write_text(STUB)
+    return [sys.executable, str(p), "--gpus", "3", "--steps", "2"]
+
+
+def test_bare_launch_starts_one_worker_per_gpu(stub):
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extra_env={"STUB_MODE": "ok"})
+    assert code == 0 and obj["n_gpus"] == 3
+    assert obj["env"]["RANK"] == "0" and obj["env"]["WORLD_SIZE"] == "3" and int(obj["env"]["MASTER_PORT"]) > 0
+    assert obj["argv"][-2:] == ["--transport", "auto"] and obj["config"]["comm"].startswith("allgather / rccl")
+
+
+def test_failing_worker_is_retried_on_the_host_transport(stub):
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extra_env={"STUB_MODE": "fail"})
+    assert code == 0
+    assert "host-staged" in obj["config"]["comm"] and "rccl attempt: worker exited with code 3" in obj["config"]["comm"]
+    assert "RCCL error 5" in obj["config"]["comm"]
+    assert obj["argv"][-2:] == ["--transport", "host"]
+
+
+def test_hang_is_killed_at_the_deadline_and_retried(stub):
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=1.5, extra_env={"STUB_MODE": "hang"})
+    assert code == 0 and "rccl attempt: timed out after" in obj["config"]["comm"]
+
+
+def test_failure_on_the_host_transport_too_is_an_error(stub, tmp_path):
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys; sys.exit(7)")
+    code, obj = bench.supervise([sys.executable, str(bad)], 2, [0, 1], "auto", deadline_s=30)
+    assert code == 1 and obj is None
+
+
+@pytest.mark.parametrize("mode", ["ok", "fail", "hang"])
+def test_one_supervisor_per_rank_agree_through_the_shared_directory(stub, tmp_path, mode):
+    """the torch.distributed.run shape: three supervisors, each owning one rank, sharing rdzv_dir"""
+    rdzv = tmp_path / "rdzv"
+    rdzv.mkdir()
+    res = {}
+
+    def run(rank):
+        res[rank] = bench.supervise(stub, 3, [rank], "auto", deadline_s=60 if mode != "hang" else 2.0, rdzv_dir=str(rdzv),
+                                    extra_env={"STUB_MODE": mode})
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert all(res[r][0] == 0 for r in range(3)), res
+    assert res[1][1] is None and res[2][1] is None and res[0][1]["n_gpus"] == 3
+    if mode == "ok":
+        assert "rccl attempt" not in res[0][1]["config"]["comm"]
+    else:
+        assert "host-staged" in res[0][1]["config"]["comm"] and "rccl attempt:" in res[0][1]["config"]["comm"]
+
+
+def test_command_line_entry_without_world_size(tmp_path):
+    """python bench.py --gpus 2 (no WORLD_SIZE): the parent only supervises — it must not import torch or need a GPU; with
+    the real worker on a box without GPUs both attempts fail and the exit code says so"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--bodies", "4096", "--deadline", "120",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    from conftest import has_gpu
+    if has_gpu():
+        pytest.skip("a GPU is present: covered by the -m gpu test")
+    assert r.returncode == 1
+    assert "attempt 0 (--transport auto) failed" in r.stderr and "attempt 1 (--transport host) failed" in r.stderr
+    assert "needs a GPU" in r.stderr

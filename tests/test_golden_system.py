@@ -32,7 +32,8 @@ def bits(a):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 3
+    assert len(FIXTURES) >= 5
+    assert sum(1 for f in FIXTURES if json.load(open(f))["order"].get("wsplit", 1) == 4) >= 2   # the wave-split order too
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
@@ -48,7 +49,7 @@ def test_oracle_reproduces_the_fixture(oracle, oracle_fast, path):
     o = fx["order"]
     for ora in (oracle, oracle_fast):
         order = O.order(summ=O.SUM_BLOCKED if o["summ"] == "blocked" else O.SUM_SEQ, block=o["block"] or 1024,
-                        nslices=o["nslices"], sub=o["sub"])
+                        nslices=o["nslices"], sub=o["sub"], wsplit=o.get("wsplit", 1))
         f = ora.forces_order(fx["pos0"], order_=order)
         assert np.array_equal(bits(f), bits(fx["forces0"]))
         p, v = fx["pos0"].copy(), fx["vel0"].copy()
@@ -70,11 +71,16 @@ def test_engine_reproduces_the_fixture(nb, path):
             eng.set_option(nb.OPT_SUM_BLOCK, o["block"])
         eng.set_option(nb.OPT_JSLICES, o["nslices"])
         eng.set_option(nb.OPT_JSUB, o["sub"])
-        for variant, iblock in ((nb.VARIANT_SMEM, 1), (nb.VARIANT_SMEM, 4), (nb.VARIANT_LDS, 2), (nb.VARIANT_READLANE, 2)):
+        ws = o.get("wsplit", 1)
+        eng.set_option(nb.OPT_WSPLIT, ws)
+        # the wave-split order exists in the scalar-delivery kernel with one body per lane; the plain one in all of them
+        shapes = ((nb.VARIANT_SMEM, 1),) if ws == 4 else ((nb.VARIANT_SMEM, 1), (nb.VARIANT_SMEM, 4), (nb.VARIANT_LDS, 2), (nb.VARIANT_READLANE, 2))
+        for variant, iblock in shapes:
             for fuse in (1, 0):
                 eng.set_option(nb.OPT_VARIANT, variant)
                 eng.set_option(nb.OPT_IBLOCK, iblock)
                 eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+                assert eng.config["wsplit"] == ws
                 assert np.array_equal(bits(eng.forces(fx["pos0"])), bits(fx["forces0"])), (variant, iblock, fuse)
                 eng.upload(fx["pos0"], fx["vel0"])
                 eng.step(fx["dt"], fx["steps"])
@@ -91,10 +97,12 @@ def test_engine_reproduces_the_fixture(nb, path):
 
 
 @pytest.mark.gpu
-def test_virtual_ranks_reproduce_the_sharded_fixture(nb, monkeypatch):
-    """system_n150_sharded.json is the order of a 4-rank job (4 slices x 2 pieces): 4 virtual ranks on this GPU must give it"""
+@pytest.mark.parametrize("name", ["system_n150_sharded.json", "system_n90_wsplit4_sharded.json"])
+def test_virtual_ranks_reproduce_the_sharded_fixture(nb, monkeypatch, name):
+    """the sharded fixtures are the orders of a 4-rank job (4 slices x 2 pieces, waves walking whole segments) and of a
+    3-rank job with the wave split: that many virtual ranks on this GPU must give them"""
     monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
-    fx = load(os.path.join(HERE, "golden", "system_n150_sharded.json"))
+    fx = load(os.path.join(HERE, "golden", name))
     o = fx["order"]
     for overlap in (1, 2, 0):
         eng = nb.NBody(fx["n"], ngpus=o["nslices"])
@@ -102,7 +110,9 @@ def test_virtual_ranks_reproduce_the_sharded_fixture(nb, monkeypatch):
             eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
             eng.set_option(nb.OPT_SUM_BLOCK, o["block"])
             eng.set_option(nb.OPT_JSUB, o["sub"])
+            eng.set_option(nb.OPT_WSPLIT, o.get("wsplit", 1))
             eng.set_option(nb.OPT_OVERLAP, overlap)
+            assert eng.config["wsplit"] == o.get("wsplit", 1)
             assert np.array_equal(bits(eng.forces(fx["pos0"])), bits(fx["forces0"]))
             eng.upload(fx["pos0"], fx["vel0"])
             eng.step(fx["dt"], fx["steps"])

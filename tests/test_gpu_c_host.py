@@ -24,12 +24,12 @@ def test_c_host_program_matches_oracle(nb, oracle_fast, extra):
     m = re.search(r"checksum \(sum of positions\): (\S+) (\S+) (\S+)", out.stdout)
     assert m, out.stdout
     got = np.array([float(m.group(k)) for k in (1, 2, 3)])
-    cfg = re.search(r"(\d+) segments, sum block (\d+), (\d+) launch", out.stdout)
+    cfg = re.search(r"(\d+) segments x (\d+) pieces, sum block (\d+), (\d+) launch", out.stdout)
     assert cfg, out.stdout
-    segments, block, launches = (int(cfg.group(k)) for k in (1, 2, 3))
-    assert block == 1024 and launches in (1, 2) and segments > 1      # the engine's own configuration
+    segments, pieces, block, launches = (int(cfg.group(k)) for k in (1, 2, 3, 4))
+    assert block == 1024 and launches in (1, 2) and segments > 1 and pieces == 4      # the engine's own configuration
     pos, vel = nb.make_bodies(n)
-    oracle_fast.step_order(pos, vel, 0.01, iters, summ=O.SUM_BLOCKED, block=block, sub=segments)
+    oracle_fast.step_order(pos, vel, 0.01, iters, summ=O.SUM_BLOCKED, block=block, sub=segments, wsplit=pieces)
     want = pos[:, :3].astype(np.float64).sum(0)
     assert np.allclose(got, want, rtol=0, atol=1e-6 * np.abs(pos[:, :3]).sum()), (got, want)   # printed with %.9g
     assert re.search(r"%d Bodies .* Billion Interactions / second" % n, out.stdout)
@@ -38,13 +38,15 @@ def test_c_host_program_matches_oracle(nb, oracle_fast, extra):
 def test_gpu_host_program_and_cpu_program_print_the_same_checksum():
     """BASELINE config 1 (CPU program, oracle/nbody_cpu) next to the GPU host program in --strict mode: identical
     initial conditions, identical arithmetic, identical checksum line — with one sequential sum per body (what a plain
-    CPU nbody.c does) and in the engine's default order (blocked sums, 16 source segments at this size, one launch/step)."""
+    CPU nbody.c does) and in the engine's orders (blocked sums; 16 segments walked whole, or the default 8 segments of four
+    pieces each)."""
     cpu = os.path.join(ROOT, "oracle", "nbody_cpu")
     assert os.path.exists(cpu) and os.path.exists(EXE)
     line = lambda out: [l for l in out.splitlines() if l.startswith("checksum")][0]
-    for cpu_args, gpu_args in (([], ["--sum", "seq", "--jsub", "1"]),
-                               (["--sum", "blocked", "--segments", "16"], ["--jsub", "16", "--one-launch"]),
-                               (["--sum", "blocked", "--block", "256", "--segments", "3"], ["--jsub", "3", "--block", "256", "--two-launch"])):
+    for cpu_args, gpu_args in (([], ["--sum", "seq", "--jsub", "1", "--wsplit", "1"]),
+                               (["--sum", "blocked", "--segments", "16"], ["--jsub", "16", "--one-launch", "--wsplit", "1"]),
+                               (["--sum", "blocked", "--segments", "8", "--wsplit", "4"], ["--jsub", "8", "--one-launch"]),
+                               (["--sum", "blocked", "--block", "256", "--segments", "3", "--wsplit", "4"], ["--jsub", "3", "--block", "256", "--two-launch", "--wsplit", "4"])):
         a = subprocess.run([cpu, "4096", "10"] + cpu_args, capture_output=True, text=True, timeout=300)
         b = subprocess.run([EXE, "4096", "10", "--strict"] + gpu_args, capture_output=True, text=True, timeout=300)
         assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr

@@ -68,7 +68,10 @@ def engine_factory(nb):
 VARIANTS = ["smem", "lds", "readlane"]
 
 
-def set_variant(nb, eng, variant, iblock, jsub=0, jslices=1, arith=None):
+def set_variant(nb, eng, variant, iblock, jsub=0, jslices=1, arith=None, wsplit=-1):
+    """wsplit: -1 = the engine's choice (4 where the kernel has the wave split: smem / isa with one body per lane), 1 = every
+    wave walks the whole segment (the only layout of the lds / readlane kernels and of 2+ bodies per lane)"""
+    eng.set_option(nb.OPT_WSPLIT, wsplit)
     eng.set_option(nb.OPT_VARIANT, {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE,
                                     "isa": nb.VARIANT_ISA, "auto": nb.VARIANT_AUTO}[variant])
     eng.set_option(nb.OPT_IBLOCK, iblock)
@@ -82,6 +85,7 @@ def test_defaults_are_the_timed_configuration(nb, engine_factory):
     eng = engine_factory(1 << 16)
     cfg = eng.config
     assert cfg["variant"] == "isa" and cfg["iblock"] == 1 and cfg["sum_order"] == "blocked" and cfg["sum_block"] == 1024
+    assert cfg["wsplit"] == 4 and eng.order["wsplit"] == 4            # 64-row workgroups, four waves split the segment
     assert cfg["launches_per_step"] == 1 and cfg["nseg"] > 1          # several segments, still one launch per step
     small = engine_factory(4096)                                      # few workgroups per CU: the hand-off would be exposed
     assert small.config["launches_per_step"] == 2 and small.config["variant"] == "isa"
@@ -139,37 +143,94 @@ def test_strict_lds_tiles(nb, oracle_fast, engine_factory, tile):
 
 
 def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engine_factory):
-    """All delivery variants and register blockings run the same operations in the same order."""
+    """All delivery variants and register blockings run the same operations in the same order (with every wave walking the
+    whole segment, the one layout they all have); and with the wave split the two kernels that have it agree."""
     n = 4096 + 37
     pos, _ = nb.make_bodies(n, seed=11)
     eng = engine_factory(n)
     ref = None
     for variant in VARIANTS:
         for iblock in (1, 2, 4):
-            set_variant(nb, eng, variant, iblock, jsub=1, arith=nb.ARITH_FMA3)
+            set_variant(nb, eng, variant, iblock, jsub=1, arith=nb.ARITH_FMA3, wsplit=1)
+            assert eng.config["wsplit"] == 1
             got = eng.forces(pos)
             if ref is None:
                 ref = got
             assert np.array_equal(bits(got), bits(ref)), (variant, iblock)
-    set_variant(nb, eng, "smem", 8, jsub=1, arith=nb.ARITH_FMA3)
+    set_variant(nb, eng, "smem", 8, jsub=1, arith=nb.ARITH_FMA3, wsplit=1)
     assert np.array_equal(bits(eng.forces(pos)), bits(ref))
     # the hand-scheduled ISA loop (both code-placement phases): same operations, same order, same bits
-    for phase in (0, 1, 2, 9, 10, 11, 12, 13, 16, 17, 18):      # 2 = staggered loads, 9..13 = other encodings of the same operations
-        set_variant(nb, eng, "isa", 0, jsub=1)
-        eng.set_option(nb.OPT_ISA_PHASE, phase)
-        assert eng.config["variant"] == "isa" and eng.config["iblock"] == 1
-        assert np.array_equal(bits(eng.forces(pos)), bits(ref)), phase
-        for jsub, jsl in ((3, 1), (2, 5)):
-            set_variant(nb, eng, "isa", 0, jsub=jsub, jslices=jsl)
-            got = eng.forces(pos)
-            set_variant(nb, eng, "smem", 1, jsub=jsub, jslices=jsl)
-            assert np.array_equal(bits(got), bits(eng.forces(pos))), (phase, jsub, jsl)
+    for phase in (0, 1):
+        for ws in (1, 4):
+            set_variant(nb, eng, "isa", 0, jsub=1, wsplit=ws)
+            eng.set_option(nb.OPT_ISA_PHASE, phase)
+            assert eng.config["variant"] == "isa" and eng.config["iblock"] == 1 and eng.config["wsplit"] == ws
+            if ws == 1:
+                assert np.array_equal(bits(eng.forces(pos)), bits(ref)), phase
+            for jsub, jsl in ((1, 1), (3, 1), (2, 5)):
+                set_variant(nb, eng, "isa", 0, jsub=jsub, jslices=jsl, wsplit=ws)
+                got = eng.forces(pos)
+                set_variant(nb, eng, "smem", 1, jsub=jsub, jslices=jsl, wsplit=ws)
+                assert eng.config["wsplit"] == ws
+                assert np.array_equal(bits(got), bits(eng.forces(pos))), (phase, ws, jsub, jsl)
     eng.set_option(nb.OPT_ISA_PHASE, 1)
-    set_variant(nb, eng, "smem", 1, jsub=1)
+    set_variant(nb, eng, "smem", 1, jsub=1, wsplit=1)
     want = oracle_forces(oracle_fast, eng, pos)
     f64 = oracle_fast.forces_f64_from_f32(pos)
     assert row_rel(ref, want).max() < TOL and row_rel(ref, f64).max() < TOL
     assert np.all(ref[:, 3] == 0)   # S/compute_store.vhd:242: the 4th word is 0
+
+
+def test_wave_split_third_level_bit_exact(nb, oracle_fast, engine_factory):
+    """NBODY_OPT_WSPLIT = 4: a workgroup owns 64 rows, wave w walks piece w of the segment, the four sums are added through
+    LDS in ascending order.  Strict arithmetic against the oracle's order with wsplit = 4 (ref_order_t), bit for bit: ragged
+    sizes incl. segments shorter than four sources (empty pieces), several slices, both combine forms, block folds inside
+    pieces; and the forces differ from the wsplit = 1 order only by re-association (same values to 1e-6)."""
+    for n in (1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, 6013):
+        pos, vel = nb.make_bodies(n, seed=300 + n)
+        eng = engine_factory(n)
+        eng.set_option(nb.OPT_SUM_BLOCK, 64)
+        for jsub, jsl in ((0, 1), (1, 1), (3, 1), (2, 3)):
+            if n < jsl:
+                continue
+            for fuse in (1, 0):
+                set_variant(nb, eng, "smem", 1, jsub=jsub, jslices=jsl, arith=nb.ARITH_STRICT, wsplit=4)
+                eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+                assert eng.config["wsplit"] == 4 and eng.order["wsplit"] == 4
+                got = eng.forces(pos)
+                want = oracle_forces(oracle_fast, eng, pos)
+                assert np.array_equal(bits(got), bits(want)), (n, jsub, jsl, fuse)
+                eng.upload(pos, vel)
+                eng.step(0.01, 3)
+                gp, gv = eng.download()
+                op, ov = pos.copy(), vel.copy()
+                oracle_step(oracle_fast, eng, op, ov, 0.01, 3)
+                assert np.array_equal(bits(gp), bits(op)) and np.array_equal(bits(gv), bits(ov)), (n, jsub, jsl, fuse)
+        if n >= 1000:
+            set_variant(nb, eng, "smem", 1, jsub=2, arith=nb.ARITH_STRICT, wsplit=4)
+            a = eng.forces(pos)
+            set_variant(nb, eng, "smem", 1, jsub=2, arith=nb.ARITH_STRICT, wsplit=1)
+            assert eng.order["wsplit"] == 1
+            b = eng.forces(pos)
+            assert not np.array_equal(bits(a), bits(b)) and row_rel(a, b).max() < 1e-5
+
+
+def test_diagnostic_loop_forms_are_not_in_the_product_library(nb, engine_factory):
+    """NBODY_OPT_ISA_PHASE 2..18 (experiment encodings; 3..8, 14, 15 are timing-only forms with WRONG results) exist only in
+    the diagnostic build (make diag): the product library refuses them and keeps running the product loop."""
+    n = 2000
+    pos, _ = nb.make_bodies(n, seed=1)
+    eng = engine_factory(n)
+    assert eng.info(nb._lib.INFO_DIAG_BUILD) == 0
+    ref = eng.forces(pos)
+    for phase in range(2, 19):
+        with pytest.raises(nb.NBodyError) as e:
+            eng.set_option(nb.OPT_ISA_PHASE, phase)
+        assert e.value.code == nb._lib.ERR_UNSUPPORTED, phase
+        assert eng.config["isa_phase"] == 1
+    assert np.array_equal(bits(eng.forces(pos)), bits(ref))
+    eng.set_option(nb.OPT_ISA_PHASE, 0)
+    assert np.array_equal(bits(eng.forces(pos)), bits(ref))
 
 
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 31, 33, 100, 1031, 1024, 2047, 2056, 3000])
@@ -287,16 +348,17 @@ def test_one_launch_combine_equals_combine_kernel(nb, engine_factory):
                 assert np.array_equal(bits(x), bits(y)), (n, variant, iblock, jsub, jsl)
     # a long run under load (many resident workgroups per CU, thousands of hand-offs per step, partial buffers and
     # tickets reused every step): any stale or torn read of a partial sum changes the final bits
-    for n, steps in ((20000, 3000), (65536 + 77, 300)):
+    for n, steps, ws, nseg in ((20000, 3000, 4, 16), (20000, 1500, 1, 64), (65536 + 77, 300, 4, 16), (65536 + 77, 150, 1, 64)):
         pos, vel = nb.make_bodies(n, seed=7)
         eng = engine_factory(n)
+        eng.set_option(nb.OPT_WSPLIT, ws)
         out = {}
         for fuse in (1, 0):
             eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
             eng.upload(pos, vel)
             eng.step(1e-4, steps)
             out[fuse] = eng.download()
-        assert eng.config["nseg"] == 64
+        assert eng.config["nseg"] == nseg and eng.config["wsplit"] == ws
         assert np.array_equal(bits(out[1][0]), bits(out[0][0])) and np.array_equal(bits(out[1][1]), bits(out[0][1])), n
     # fp64 words (two 16-byte stores per partial)
     n = 5000
@@ -542,14 +604,20 @@ def test_config4_workload_eight_virtual_ranks(nb, oracle_fast, engine_factory, m
     one.step(dt, steps)
     wp, wv = one.download()
     assert np.array_equal(bits(mp), bits(wp)) and np.array_equal(bits(mv), bits(wv))
-    one.upload(pos, vel)
+    # the row sample on the SHARDED engine itself (global body indices; windows that straddle two ranks' slices included)
+    multi = engine_factory(n, ngpus=P)
+    multi.upload(pos, vel)
     worst = 0.0
-    for first, cnt in shard_edge_rows(n, P, 32):
-        got = one.forces_rows(first, cnt)
-        want = oracle_forces(oracle_fast, one, pos[first:first + cnt], pos)
+    per = n // P
+    for first, cnt in shard_edge_rows(n, P, 32) + [(q * per - 16, 32) for q in range(1, P)]:
+        got = multi.forces_rows(first, cnt)
+        want = oracle_forces(oracle_fast, multi, pos[first:first + cnt], pos)
         f64 = oracle_fast.forces_f64_from_f32(pos[first:first + cnt], pos)
         worst = max(worst, row_rel(got, want).max(), row_rel(got, f64).max())
     assert worst < TOL, worst
+    multi.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    for first, cnt in ((per - 16, 32), (5 * per - 3, 40)):
+        assert np.array_equal(bits(multi.forces_rows(first, cnt)), bits(oracle_forces(oracle_fast, multi, pos[first:first + cnt], pos))), first
 
 
 def test_config5_workload_fp64(nb, oracle_fast, engine_factory):

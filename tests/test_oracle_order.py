@@ -11,32 +11,50 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def emulate(ora, pos, rows, nslices, sub, block, nb):
-    """segments in ascending order; inside a segment blocks of `block` sources, each summed by the sequential kernel
-    from zero, block sums added in ascending order starting from +0; segment sums: F = p0, F = F + p_s"""
+def emulate(ora, pos, rows, nslices, sub, block, nb, wsplit=1):
+    """segments in ascending order; a segment is cut into `wsplit` pieces (ceil(len / wsplit) sources each); inside a piece
+    blocks of `block` sources, each summed by the sequential kernel from zero, block sums added in ascending order starting
+    from +0; piece sums: S = w0, S = S + w_k; segment sums: F = p0, F = F + p_s"""
     n = len(pos)
     total = None
     for q in range(nslices):
         for t in range(sub):
-            b, e = nb.sharding.segment_bounds(q, t, n, nslices, sub)
-            seg = np.zeros_like(rows)
-            for j0 in range(b, e, block):
-                part = ora.forces_f32(rows, pos[j0:min(j0 + block, e)])
-                seg = (seg + part).astype(np.float32)
+            sb, se = nb.sharding.segment_bounds(q, t, n, nslices, sub)
+            seg = None
+            for w in range(wsplit):
+                b, e = nb.sharding.piece_bounds(sb, se, w, wsplit)
+                pc = np.zeros_like(rows)
+                for j0 in range(b, e, block):
+                    part = ora.forces_f32(rows, pos[j0:min(j0 + block, e)])
+                    pc = (pc + part).astype(np.float32)
+                seg = pc if seg is None else (seg + pc).astype(np.float32)
             total = seg if total is None else (total + seg).astype(np.float32)
     total[:, 3] = 0
     return total
 
 
-@pytest.mark.parametrize("n,nslices,sub,block", [(700, 1, 1, 64), (700, 1, 1, 1024), (1500, 3, 2, 128), (1029, 8, 1, 64), (64, 1, 4, 64), (5, 2, 2, 64)])
-def test_blocked_order_equals_emulation(nb, oracle, oracle_fast, n, nslices, sub, block):
+@pytest.mark.parametrize("n,nslices,sub,block,wsplit", [(700, 1, 1, 64, 1), (700, 1, 1, 1024, 1), (1500, 3, 2, 128, 1), (1029, 8, 1, 64, 1),
+                                                        (64, 1, 4, 64, 1), (5, 2, 2, 64, 1),
+                                                        (700, 1, 1, 64, 4), (1500, 3, 2, 64, 4), (1029, 8, 1, 64, 4), (5, 2, 2, 64, 4), (3, 1, 1, 64, 4)])
+def test_blocked_order_equals_emulation(nb, oracle, oracle_fast, n, nslices, sub, block, wsplit):
     pos, _ = nb.make_bodies(n, seed=n)
     for ora in (oracle, oracle_fast):
-        got = ora.forces_order(pos, summ=O.SUM_BLOCKED, block=block, nslices=nslices, sub=sub)
-        assert np.array_equal(bits(got), bits(emulate(ora, pos, pos, nslices, sub, block, nb)))
+        got = ora.forces_order(pos, summ=O.SUM_BLOCKED, block=block, nslices=nslices, sub=sub, wsplit=wsplit)
+        assert np.array_equal(bits(got), bits(emulate(ora, pos, pos, nslices, sub, block, nb, wsplit)))
     # the two builds agree bit for bit (the fast one is what the GPU tests use)
-    assert np.array_equal(bits(oracle.forces_order(pos, block=block, nslices=nslices, sub=sub)),
-                          bits(oracle_fast.forces_order(pos, block=block, nslices=nslices, sub=sub)))
+    assert np.array_equal(bits(oracle.forces_order(pos, block=block, nslices=nslices, sub=sub, wsplit=wsplit)),
+                          bits(oracle_fast.forces_order(pos, block=block, nslices=nslices, sub=sub, wsplit=wsplit)))
+
+
+def test_piece_bounds_tile_the_segment(nb):
+    """the four waves' pieces: contiguous, ascending, ceil(len / 4) each, the last ones shorter or empty"""
+    for sb, se in ((0, 0), (0, 1), (5, 8), (0, 4), (10, 15), (100, 380), (7, 131079)):
+        prev = sb
+        for w in range(4):
+            b, e = nb.sharding.piece_bounds(sb, se, w, 4)
+            assert b == prev and b <= e <= se and e - b <= -(-(se - sb) // 4)
+            prev = e
+        assert prev == se
 
 
 def test_sequential_order_is_the_classic_entry_point(nb, oracle):

@@ -447,6 +447,10 @@ def main():
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
         f.write("#define NB_FORCE_LOOP_GROUP %d\n" % GROUP)
+        # Everything below up to NB_FORCE_LOOP_LONG exists only in the diagnostic build (`make diag`, -DNBODY_DIAG_LOOPS ->
+        # libnbody_hip_diag.so): experiment encodings of the same operations (bit-identical, slower) and TIMING-ONLY forms
+        # with wrong results.  The product library holds V0, V1 and LONG only and refuses the other NBODY_OPT_ISA_PHASE values.
+        f.write("#ifdef NBODY_DIAG_LOOPS\n")
         ins = build(15 - HEAD_BYTES // 4, SHORT, stagger=True)
         assert check(ins) == (60, 4)
         f.write("#define NB_FORCE_LOOP_V2 \"%s\"\n" % "\\n\\t".join(ins))
@@ -464,6 +468,7 @@ def main():
         for v, kind in ((6, "indep"), (7, "e32"), (8, "vgprsrc"), (14, "vgprsrc_rsq"), (15, "vgprsrc_rsq_lds")):
             ins = build(15 - HEAD_BYTES // 4, diag=kind)
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
+        f.write("#endif  // NBODY_DIAG_LOOPS\n")
         ins = build(15 - HEAD_BYTES // 4, LONG)
         assert check(ins) == (60, 4)
         f.write("#define NB_FORCE_LOOP_LONG \"%s\"\n" % "\\n\\t".join(ins))

@@ -64,6 +64,7 @@ def main():
         k = bench["config"]["kernel"]
         cfg = {"n": bench["config"]["n_bodies"], "dtype": bench["dtype"], "n_gpus": bench["n_gpus"], "variant": k["variant"], "iblock": k["iblock"],
                "nseg": k["nseg"], "sum_order": k["sum_order"], "sum_block": k["sum_block"], "launches_per_step": k["launches_per_step"],
+               "wsplit": k.get("wsplit", 1), "isa_phase": k.get("isa_phase", 1), "long_buffers": k.get("long_buffers", -1), "xcd_map": k.get("xcd_map", -1),
                "kernel_source_sha": bench["config"].get("kernel_source_sha")}
         wave_pairs = float(k["n_local"]) * bench["config"]["n_bodies"] / 64.0
     if durs and "GRBM_GUI_ACTIVE" in avg:
@@ -73,6 +74,10 @@ def main():
         derived["clock_ghz"] = cycles / t / 1e9
         if wave_pairs:
             derived["cycles_per_wave_pair"] = cycles * 1024.0 / wave_pairs      # 1024 SIMDs
+    if "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
+        # rocprof's classic VALUBusy = SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE; the counter is summed over the waves
+        # whose VALU instruction is in the pipe, so it passes 1 when instructions of several waves overlap there
+        derived["sq_valu_busy"] = avg["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (avg["GRBM_GUI_ACTIVE"] / 8.0)
     if avg.get("SQ_WAVE_CYCLES"):
         wc = avg["SQ_WAVE_CYCLES"]
         # SQ_* cycle counters are in quad-cycles summed over waves; MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES

@@ -2,7 +2,7 @@
 """Kernel configuration sweep on one GPU: (variant, bodies per lane, source sub-segments) -> G pairs/s from the
 HIP-event time of the force kernels.  One process, interleaved rounds (cdna guide §5.4 rule 24).
 usage: python tools/sweep.py [--n N] [--steps K] [--rounds M] [--configs "smem:4:1,lds:2:4,isa1:1:8:0:sum=seq:fuse=0,..."]
-config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked][:blk=K][:fuse=0|1][:long=0|1][:xcd=-1|0|1]"""
+config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked][:blk=K][:fuse=0|1][:long=0|1][:xcd=-1|0|1][:ws=1|4]"""
 import argparse
 import importlib
 import os
@@ -52,9 +52,10 @@ def main():
             eng.set_option(nb.OPT_FUSE_COMBINE, int(opts.get("fuse", -1)))
             eng.set_option(nb.OPT_ISA_LONG_BUFFERS, int(opts.get("long", -1)))
             eng.set_option(nb.OPT_XCD_MAP, int(opts.get("xcd", -1)))
+            eng.set_option(nb.OPT_WSPLIT, int(opts.get("ws", -1)))
             eng.set_option(nb.OPT_WAVES_PER_SIMD, w)
             eng.set_option(nb.OPT_VARIANT, vmap[v])
-            eng.set_option(nb.OPT_ISA_PHASE, int(v[3:]) if v.startswith("isa") else 0)
+            eng.set_option(nb.OPT_ISA_PHASE, int(v[3:]) if v.startswith("isa") else 1)
             eng.set_option(nb.OPT_IBLOCK, r)
             eng.set_option(nb.OPT_JSUB, s)
             eng.upload(pos, vel)
@@ -74,7 +75,7 @@ def main():
     bound = 256 * 4 * 64 / 30 * 2.4
     print("# n=%d steps=%d rounds=%d; issue bound %.0f G/s at 2.4 GHz" % (n, args.steps, args.rounds, bound))
     for c in sorted(cfgs, key=lambda c: -max(res[c])):
-        print("%-9s R=%d jsub=%-3d waves/SIMD<=%d %-24s best %7.1f  median %7.1f G pairs/s  (%.1f %% of issue bound)  %9.2f us/step"
+        print("%-9s R=%d jsub=%-3d waves/SIMD<=%d %-32s best %7.1f  median %7.1f G pairs/s  (%.1f %% of issue bound)  %9.2f us/step"
               % (c[0], c[1], c[2], c[3] or 8, " ".join(c[4]), max(res[c]), sorted(res[c])[len(res[c]) // 2], 100 * max(res[c]) / bound,
                  1e6 * float(n) * n / (max(res[c]) * 1e9)), flush=True)
     eng.close()
