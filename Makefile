@@ -15,6 +15,13 @@ lib: $(PKG)/libnbody_hip.so
 $(PKG)/libnbody_hip.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/force_loop_gfx950.inc include/nbody.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/nbody_hip.hip -ldl
 
+# The diagnostic library: the same source with -DNBODY_DIAG_LOOPS — the experiment encodings of the hand-scheduled loop and its
+# TIMING-ONLY forms (wrong results) that profiles/r02_loop_diagnostics.md was measured with.  Not part of `all`, never loaded by
+# the package unless NBODY_LIB points at it (tools/profile_diag.sh does).
+diag: $(PKG)/libnbody_hip_diag.so
+$(PKG)/libnbody_hip_diag.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/force_loop_gfx950.inc include/nbody.h
+	$(HIPCC) $(HIPFLAGS) -DNBODY_DIAG_LOOPS -shared -o $@ $(CSRC)/nbody_hip.hip -ldl
+
 # C host program (north_star: "host code stays in C"): links only the C-ABI
 host: build/nbody
 build/nbody: $(PKG)/host/nbody.c include/nbody.h include/nbody_ic.h $(PKG)/libnbody_hip.so
@@ -48,7 +55,7 @@ isa: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp
 	cd build/isa && $(HIPCC) $(HIPFLAGS) -c ../../$(CSRC)/nbody_hip.hip -save-temps -Rpass-analysis=kernel-resource-usage -o nbody_hip.o 2> resource_usage.txt
 
 clean:
-	rm -rf build $(PKG)/libnbody_hip.so
+	rm -rf build $(PKG)/libnbody_hip.so $(PKG)/libnbody_hip_diag.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib host oracle microbench isa gen clean
+.PHONY: all lib diag host oracle microbench isa gen clean

@@ -68,7 +68,8 @@ enum {
   NBODY_OPT_FUSE_COMBINE = 14, /* 1: the segments' partial sums are added by the last wave to arrive, inside the force launch (one
                               launch per step); 0: a separate combine kernel; -1 (default): one launch when the launch has
                               >= 4 workgroups per CU, where the hand-off hides behind other workgroups, else two.  Same bits. */
-  NBODY_OPT_GRAPH = 12,    /* 1 (default): nbody_step on one GPU replays a HIP graph of two steps; 0: launch every kernel */
+  NBODY_OPT_GRAPH = 12,    /* nbody_step on one GPU replays a captured HIP graph of an even number of steps: 1 (default) = 8 steps per graph
+                              once a call brings 16, else 2; k >= 2 = k steps per graph; 0: launch every kernel */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
   NBODY_OPT_WSPLIT = 17,   /* 4: a workgroup owns 64 bodies and its four waves walk a quarter of the source segment each; the four sums
                               are added through LDS in ascending source order (a third level of the sum, like the reference's 16
@@ -150,9 +151,11 @@ int nbody_comm_selftest_virtual(int vranks, int form, long long *bytes_moved);
  * pairs of one group go into one ncclGroupStart/End.  Pure host arithmetic: needs no GPU and no context.  ops may be NULL
  * (count only); *n_ops = nranks - 1. */
 int nbody_comm_plan(int form, int rank, int nranks, int n, long long *ops, int max_ops, int *n_ops);
-/* One RCCL ring step (grouped ncclSend to rank+1 / ncclRecv from rank-1) of `bytes` on the transfer stream, timed from
- * enqueue to completion with HIP events: when = 0 alone, 1 enqueued just before a full force pass, 2 just after it (the
- * force launch occupies every CU).  *force_ms = duration of that force pass (0 for when = 0).  Needs a communicator. */
+/* One RCCL ring step (grouped ncclSend to rank+1 / ncclRecv from rank-1) of `bytes` on the transfer stream, timed with HIP
+ * events: when = 0 alone, 1 enqueued just before a full force pass, 2 just after it (the force launch occupies every CU)
+ * — enqueue to completion; 3 = the steady state of a multi-GPU step (ring step and the next force pass both released by
+ * the end of the previous pass), 4 = the same with the hand-shake nbody_step() uses — from the previous pass's end to the
+ * ring step's completion.  *force_ms = duration of the (last) force pass (0 for when = 0).  Needs a communicator. */
 int nbody_comm_probe(long long bytes, int when, double *comm_ms, double *force_ms);
 void nbody_shutdown(void);
 

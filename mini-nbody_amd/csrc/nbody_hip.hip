@@ -46,6 +46,7 @@ int g_last_line = 0;
 constexpr int kMaxLocal = 16;
 constexpr int kMaxRanks = 64;
 constexpr int kTimerRing = 256;
+constexpr int kGraphSteps = 32;    // steps per replayed HIP graph once a call brings at least twice as many
 
 struct Rccl {
   void* handle = nullptr;
@@ -98,6 +99,7 @@ struct Local {
   int cur = 0;
   bool all_present = true;             // pos[cur] holds every slice
   hipEvent_t ev_own_ready = nullptr;   // the rank's slice of pos[cur] is written
+  hipEvent_t ev_comm_go = nullptr;     // the transfer stream has seen ev_own_ready: its RCCL kernel is next on its queue
   hipEvent_t ev_gather[kMaxRanks] = {};
   ncclComm_t comm_h = nullptr;
   EventTimer kern;   // force kernels (NBODY_OPT_TIMING)
@@ -124,7 +126,7 @@ struct Global {
   // replayed by nbody_step when one GPU runs many short steps (launch-bound regime)
   hipGraphExec_t step_graph = nullptr;
   bool stepped_eagerly = false;   // a step has been launched outside a capture since nbody_init
-  float graph_dt = 0.f; double graph_dt64 = 0.0; int graph_cur = -1;
+  float graph_dt = 0.f; double graph_dt64 = 0.0; int graph_cur = -1, graph_len = 0;
   bool init = false;
   int n = 0, fp64 = 0, tile = 256;
   int nranks = 1, nlocal = 0;
@@ -134,6 +136,7 @@ struct Global {
   // resolved launch configuration
   int variant = NBODY_VARIANT_SMEM, R = 4, sub = 1, nslices = 1, nseg = 1, fuse = 1;
   int wsplit = 1;                 // 4: a workgroup owns 64 rows, its four waves walk a quarter of the segment each (ForceArgs::wsplit)
+  bool comm_go_armed = false;     // the gather just enqueued recorded ev_comm_go (RCCL transport)
   bool tickets_dirty = false;     // a step failed after some of its launches: the arrival counters may be non-zero
   int cu_count = 0, clock_khz = 0;
   int comm_priority = 0;          // HIP priority of the transfer streams (0 = default)
@@ -175,7 +178,8 @@ void resolve_config() {
   // automatic: wherever it exists, except for NBODY_SUM_SEQ in fp32, whose meaning is ONE sequential sum per segment (what a CPU
   // nbody.c does); fp64 contexts, which always sum sequentially and have 29 bits to spare, take the split
   const bool auto_split = g.fp64 || g.opt.sum_order != NBODY_SUM_SEQ;
-  g.wsplit = (can_split && (g.opt.wsplit == 4 || (g.opt.wsplit < 0 && auto_split))) ? 4 : 1;
+  g.wsplit = !can_split ? 1 : (g.opt.wsplit == 4 || g.opt.wsplit == 16) ? g.opt.wsplit : (g.opt.wsplit < 0 && auto_split) ? 4 : 1;
+  if (g.wsplit == 16 && g.variant == NBODY_VARIANT_ISA && !g.fp64 && g.opt.isa_phase > 1) g.wsplit = 4;   // diagnostic loop forms: 4 waves
   // Small launches and large ones want different things (profiles/r02_small_n.md, one process, wall clock per step):
   //   large (even 64 segments give >= 16 workgroups per CU; N >= 16384 on one GPU): many short segments for load
   //     balance over the 256 CUs — 128 workgroups per CU in the launch, up to 64 segments of >= 128 sources (N = 65536:
@@ -253,6 +257,7 @@ int alloc_local(Local& L) {
   HIPC(hipMemset(L.vel, 0, (L.n_local + pad) * wb));
   HIPC(hipMemset(L.force, 0, (L.n_local + pad) * wb));
   HIPC(hipEventCreateWithFlags(&L.ev_own_ready, hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&L.ev_comm_go, hipEventDisableTiming));
   for (int s = 0; s < g.nranks && s < kMaxRanks; ++s) HIPC(hipEventCreateWithFlags(&L.ev_gather[s], hipEventDisableTiming));
   for (EventTimer* T : {&L.kern, &L.wait})
     for (int k = 0; k < kTimerRing; ++k) { HIPC(hipEventCreate(&T->t0[k])); HIPC(hipEventCreate(&T->t1[k])); }
@@ -333,11 +338,11 @@ int launch_timed(Local& L, K kernel, dim3 grid, const ForceArgs& a) {
   // optional occupancy cap: k workgroups (= k waves per SIMD) per CU by giving each 160 KiB / k of dynamic LDS
   size_t dyn_lds = 0;
   if (g.opt.waves_per_simd > 0 && g.opt.waves_per_simd < 8) {
-    const size_t static_lds = (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0) + (a.wsplit > 1 ? 3 * 64 * word_bytes() : 0);
+    const size_t static_lds = (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0) + (a.wsplit > 1 ? (size_t)(a.wsplit - 1) * 64 * word_bytes() : 0);
     dyn_lds = (size_t)(160 * 1024) / (size_t)g.opt.waves_per_simd - 512 - static_lds;
     if (dyn_lds > 64 * 1024) HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
-  hipLaunchKernelGGL(kernel, grid, dim3(kBlock), dyn_lds, L.compute, a);
+  hipLaunchKernelGGL(kernel, grid, dim3(wg_threads(a.wsplit)), dyn_lds, L.compute, a);
   HIPC(hipGetLastError());
   return timer_end(L.kern, L.compute, slot);
 }
@@ -355,7 +360,10 @@ int launch_f32_RA(Local& L, dim3 grid, const ForceArgs& a) {
       case NBODY_VARIANT_READLANE:
         return launch_timed(L, force_readlane_f32<R, ARITH>, grid, a);
       default:
-        if constexpr (R == 1) { if (a.wsplit > 1) return launch_timed(L, force_smem_f32<1, ARITH, 4>, grid, a); }
+        if constexpr (R == 1) {
+          if (a.wsplit == 16) return launch_timed(L, force_smem_f32<1, ARITH, 16>, grid, a);
+          if (a.wsplit == 4) return launch_timed(L, force_smem_f32<1, ARITH, 4>, grid, a);
+        }
         return launch_timed(L, force_smem_f32<R, ARITH, 1>, grid, a);
     }
   }
@@ -374,11 +382,15 @@ int launch_f32_R(Local& L, dim3 grid, const ForceArgs& a) {
 // the hand-scheduled fp32 loop in form PH (NBODY_OPT_ISA_PHASE), with or without the wave split
 template <int PH>
 int launch_isa_f32(Local& L, dim3 grid, const ForceArgs& a) {
-  return a.wsplit > 1 ? launch_timed(L, force_isa_f32<PH, 4>, grid, a) : launch_timed(L, force_isa_f32<PH, 1>, grid, a);
+  if constexpr (PH <= 1) {   // the 16-wave form exists for the product loop and its placement twin (resolve_config sees to it)
+    if (a.wsplit == 16) return launch_timed(L, force_isa_f32<PH, 16>, grid, a);
+  }
+  return a.wsplit == 4 ? launch_timed(L, force_isa_f32<PH, 4>, grid, a) : launch_timed(L, force_isa_f32<PH, 1>, grid, a);
 }
 template <int PH>
 int launch_isa_f64(Local& L, dim3 grid, const ForceArgs& a) {
-  return a.wsplit > 1 ? launch_timed(L, force_isa_f64<PH, 4>, grid, a) : launch_timed(L, force_isa_f64<PH, 1>, grid, a);
+  if (a.wsplit == 16) return launch_timed(L, force_isa_f64<PH, 16>, grid, a);
+  return a.wsplit == 4 ? launch_timed(L, force_isa_f64<PH, 4>, grid, a) : launch_timed(L, force_isa_f64<PH, 1>, grid, a);
 }
 
 // loop forms that exist in the diagnostic build only (make diag): experiment encodings and timing-only forms
@@ -429,14 +441,16 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   const bool xcd_ok = grid.y % 8 == 0 || ((grid.y == 1 || grid.y == 2 || grid.y == 4) && grid.x % (8 / grid.y) == 0);
   const bool xcd_auto = (long long)blocks_for(row_count, 1, 1) >= 4096;
   a.xcd_map = ((g.opt.xcd_map > 0 || (g.opt.xcd_map < 0 && xcd_auto)) && xcd_ok) ? 1 : 0;
-  a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y < 32LL * cus ? 1 : 0) : g.opt.long_buffers;
+  a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y * (wg_threads(a.wsplit) / 64) < 128LL * cus ? 1 : 0) : g.opt.long_buffers;
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
     if (g.opt.isa_phase == 2) return launch_isa_f64<2>(L, grid, a);
     return g.opt.isa_phase == 0 ? launch_isa_f64<0>(L, grid, a) : launch_isa_f64<1>(L, grid, a);
   }
   if (g.fp64) {
     switch (R) {
-      case 1: return a.wsplit > 1 ? launch_timed(L, force_smem_f64<1, 4>, grid, a) : launch_timed(L, force_smem_f64<1, 1>, grid, a);
+      case 1:
+        if (a.wsplit == 16) return launch_timed(L, force_smem_f64<1, 16>, grid, a);
+        return a.wsplit == 4 ? launch_timed(L, force_smem_f64<1, 4>, grid, a) : launch_timed(L, force_smem_f64<1, 1>, grid, a);
       case 2: return launch_timed(L, force_smem_f64<2, 1>, grid, a);
       default: return launch_timed(L, force_smem_f64<4, 1>, grid, a);
     }
@@ -450,7 +464,10 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
     }
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
-    if (a.long_buffers) return a.wsplit > 1 ? launch_timed(L, force_isa_long_f32<4>, grid, a) : launch_timed(L, force_isa_long_f32<1>, grid, a);
+    if (a.long_buffers) {
+      if (a.wsplit == 16) return launch_timed(L, force_isa_long_f32<16>, grid, a);
+      return a.wsplit == 4 ? launch_timed(L, force_isa_long_f32<4>, grid, a) : launch_timed(L, force_isa_long_f32<1>, grid, a);
+    }
     switch (g.opt.isa_phase) {
       case 0: return launch_isa_f32<0>(L, grid, a);
 #ifdef NBODY_DIAG_LOOPS
@@ -644,6 +661,13 @@ int enqueue_gather(int buf) {
     return NBODY_OK;
   }
   HIPC(hipStreamWaitEvent(L.comm, L.ev_own_ready, 0));
+  // "the transfer stream has got this far": the own-slice force launch waits for it (enqueue_step), so that the RCCL kernel's
+  // packet is at the head of its queue when that launch is released.  Without it both are released by the previous step's
+  // end, the force launch wins and fills every wave slot, and the RCCL kernel starts only when that launch has drained:
+  // measured on one GPU (profiles/r03_comm_under_load.md) 236 ms after the release without the hand-shake, 0.03 ms with it;
+  // the stream's priority changes neither.
+  HIPC(hipEventRecord(L.ev_comm_go, L.comm));
+  g.comm_go_armed = true;
   return rccl_gather(L, L.pos[buf], L.ev_gather);
 }
 
@@ -673,7 +697,9 @@ int enqueue_step_impl(float dt, double dt64) {
     // onto the device ahead of the force launch that fills every CU; the host-staged exchange blocks the host, so
     // there the force launch goes first.
     const bool host_staged = g.multiprocess && g.host_gather;
+    g.comm_go_armed = false;
     if (!host_staged) NBC(enqueue_gather(g.loc[0].cur));
+    if (g.comm_go_armed) HIPC(hipStreamWaitEvent(g.loc[0].compute, g.loc[0].ev_comm_go, 0));   // RCCL transport: see enqueue_gather
     for (int l = 0; l < g.nlocal; ++l) NBC(launch_force(g.loc[l], 0, g.loc[l].n_local, g.loc[l].rank, 1, fin, dt, dt64));
     if (host_staged) NBC(enqueue_gather(g.loc[0].cur));
   }
@@ -704,7 +730,9 @@ int enqueue_step_impl(float dt, double dt64) {
       NBC(launch_force(L, 0, L.n_local, L.rank, P, fin, dt, dt64));
     }
     NBC(launch_combine(L, 0, L.n_local, fin, dt, dt64));
-    HIPC(hipEventRecord(L.ev_own_ready, L.compute));
+    // "own slice of pos[cur^1] written": what the next step's transfers wait for.  With one rank nothing does, and inside a
+    // captured graph the record would be a node between two kernels.
+    if (P > 1) HIPC(hipEventRecord(L.ev_own_ready, L.compute));
   }
   for (int l = 0; l < g.nlocal; ++l) {
     Local& L = g.loc[l];
@@ -776,6 +804,7 @@ void free_local(Local& L) {
   if (L.tickets) (void)hipFree(L.tickets);
   if (L.full_scratch) (void)hipFree(L.full_scratch);
   if (L.ev_own_ready) (void)hipEventDestroy(L.ev_own_ready);
+  if (L.ev_comm_go) (void)hipEventDestroy(L.ev_comm_go);
   for (int s = 0; s < kMaxRanks; ++s) if (L.ev_gather[s]) (void)hipEventDestroy(L.ev_gather[s]);
   for (EventTimer* T : {&L.kern, &L.wait})
     for (int k = 0; k < kTimerRing; ++k) { if (T->t0[k]) (void)hipEventDestroy(T->t0[k]); if (T->t1[k]) (void)hipEventDestroy(T->t1[k]); }
@@ -884,26 +913,35 @@ int step_impl(float dt, double dt64, int nsteps) {
     // whichever buffer is current and however often the graph is reused (profiles/r02_small_n.md).  So the first step of
     // an engine's life is always launched eagerly.
     if (!g.stepped_eagerly) { NBC(enqueue_step(dt, dt64)); ++s; g.stepped_eagerly = true; }
-    if (!g.step_graph || g.graph_cur != L.cur || g.graph_dt != dt || g.graph_dt64 != dt64) {
+    // steps per graph: an even number (the position buffers swap every step, so an even count returns to the same state).
+    // Every graph launch is a boundary of its own on the queue and a host call, and a step at N = 4096 is only 10 us:
+    // measured per step (profiles/r03_small_n.md) N = 1024: 11.0 us with 2 steps per graph, 9.2 with 8, 8.8 with 64;
+    // N = 4096: 12.5 / 10.7 / 10.2; N = 16384: 71.9 / 69.6 / 69.1.  NBODY_OPT_GRAPH = 1: 32 steps per graph when the call
+    // brings >= 64, 16 from 32, 8 from 16, else 2; k >= 2: k steps per graph.
+    const int left = nsteps - s;
+    int len = g.opt.graph >= 2 ? (g.opt.graph & ~1) : (left >= 2 * kGraphSteps ? kGraphSteps : left >= kGraphSteps ? kGraphSteps / 2 : left >= kGraphSteps / 2 ? kGraphSteps / 4 : 2);
+    if (len > nsteps - s) len = (nsteps - s) & ~1;
+    if (len >= 2 && (!g.step_graph || g.graph_len != len || g.graph_cur != L.cur || g.graph_dt != dt || g.graph_dt64 != dt64)) {
       drop_step_graph();
       hipGraph_t graph = nullptr;
       const long long done = g.steps_done;
       const int cur0 = L.cur;
       const bool present0 = L.all_present;
       HIPC(hipStreamBeginCapture(L.compute, hipStreamCaptureModeThreadLocal));
-      int rc = enqueue_step(dt, dt64);
-      if (!rc) rc = enqueue_step(dt, dt64);
+      int rc = 0;
+      for (int k = 0; k < len && !rc; ++k) rc = enqueue_step(dt, dt64);
       hipError_t e = hipStreamEndCapture(L.compute, &graph);
       g.steps_done = done;                       // capturing executes nothing
-      L.cur = cur0; L.all_present = present0;    // two steps return to the same buffer; a failed capture may have toggled once
+      L.cur = cur0; L.all_present = present0;    // an even number of steps returns to the same buffer; a failed capture may have toggled
+      g.tickets_dirty = false;                   // ... and has launched nothing
       if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       if (e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); g_last_line = __LINE__; return (int)e; }
       e = hipGraphInstantiate(&g.step_graph, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIPC(e);
-      g.graph_cur = L.cur; g.graph_dt = dt; g.graph_dt64 = dt64;
+      g.graph_cur = L.cur; g.graph_dt = dt; g.graph_dt64 = dt64; g.graph_len = len;
     }
-    for (; s + 2 <= nsteps; s += 2) { HIPC(hipGraphLaunch(g.step_graph, L.compute)); g.steps_done += 2; }
+    if (len >= 2) for (; s + len <= nsteps; s += len) { HIPC(hipGraphLaunch(g.step_graph, L.compute)); g.steps_done += len; }
   }
   if (s < nsteps) g.stepped_eagerly = true;
   for (; s < nsteps; ++s) NBC(enqueue_step(dt, dt64));
@@ -1263,30 +1301,37 @@ int nbody_comm_plan(int form, int rank, int nranks, int n, long long* ops, int m
 }
 
 // How long one RCCL ring step of `bytes` (ncclSend to rank+1 / ncclRecv from rank-1, one group) takes on the transfer
-// stream, from the moment it is enqueued: alone (when = 0), enqueued just BEFORE a full force pass on the compute stream
-// (when = 1) or just AFTER it (when = 2) — the force launch fills every wave slot of every CU, so this is what a
-// transfer costs beside it.  *comm_ms: enqueue -> done on the transfer stream (HIP events); *force_ms: the force pass.
+// stream beside a force pass that fills every wave slot of every CU.  when =
+//   0  alone;                                  *comm_ms = enqueue -> done of the ring step
+//   1  enqueued just BEFORE a full force pass;  "
+//   2  enqueued just AFTER it;                  "
+//   3  the steady state of a multi-GPU step: force pass A, then — both released by A's end — the ring step on the
+//      transfer stream and force pass B on the compute stream; *comm_ms = end of A -> ring step done (B's duration when
+//      the transfer loses the race for the chip, microseconds when it wins);
+//   4  the same with the hand-shake enqueue_step() uses: pass B waits for an event the transfer stream records right
+//      before its RCCL kernel (L.ev_comm_go), so the RCCL kernel's packet is at the head of its queue when B is released.
+// *force_ms: the duration of the (last) force pass.
 int nbody_comm_probe(long long bytes, int when, double* comm_ms, double* force_ms) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (!g.multiprocess) return NBODY_ERR_STATE;
   Local& L = g.loc[0];
   if (!L.comm_h) return NBODY_ERR_STATE;
   const size_t wb = word_bytes();
-  if (bytes <= 0 || when < 0 || when > 2 || (size_t)bytes * 2 > (size_t)g.n * wb) return NBODY_ERR_ARG;
+  if (bytes <= 0 || when < 0 || when > 4 || (size_t)bytes * 2 > (size_t)g.n * wb) return NBODY_ERR_ARG;
   NBC(reconfigure());
   NBC(complete_positions());
   NBC(sync_all());
   HIPC(hipSetDevice(L.device));
   if (!L.full_scratch) HIPC(hipMalloc(&L.full_scratch, (size_t)(g.n + 64) * wb));
-  struct Ev4 { hipEvent_t e[4] = {}; ~Ev4() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } ev;
+  struct Evs { hipEvent_t e[6] = {}; ~Evs() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } ev;
   for (hipEvent_t& x : ev.e) HIPC(hipEventCreate(&x));
   const Finish fin = {false, false, true};
-  auto force_pass = [&]() -> int {
-    HIPC(hipEventRecord(ev.e[2], L.compute));
+  auto force_pass = [&](hipEvent_t begin, hipEvent_t end) -> int {
+    if (begin) HIPC(hipEventRecord(begin, L.compute));
     int rc = launch_force(L, 0, L.n_local, g.nslices - 1, g.nslices, fin, 0.f, 0.0);
     if (!rc) rc = launch_combine(L, 0, L.n_local, fin, 0.f, 0.0);
     if (rc) { g.tickets_dirty = true; return rc; }
-    HIPC(hipEventRecord(ev.e[3], L.compute));
+    HIPC(hipEventRecord(end, L.compute));
     return NBODY_OK;
   };
   auto comm_step = [&]() -> int {
@@ -1295,12 +1340,21 @@ int nbody_comm_probe(long long bytes, int when, double* comm_ms, double* force_m
     HIPC(hipEventRecord(ev.e[1], L.comm));
     return NBODY_OK;
   };
-  if (when == 1) { NBC(comm_step()); NBC(force_pass()); }
-  else if (when == 2) { NBC(force_pass()); NBC(comm_step()); }
-  else NBC(comm_step());
+  hipEvent_t from = ev.e[0];
+  if (when == 1) { NBC(comm_step()); NBC(force_pass(ev.e[2], ev.e[3])); }
+  else if (when == 2) { NBC(force_pass(ev.e[2], ev.e[3])); NBC(comm_step()); }
+  else if (when >= 3) {
+    NBC(force_pass(nullptr, ev.e[4]));                       // pass A; e[4] = "own slice ready"
+    HIPC(hipStreamWaitEvent(L.comm, ev.e[4], 0));
+    if (when == 4) HIPC(hipEventRecord(L.ev_comm_go, L.comm));
+    NBC(comm_step());
+    if (when == 4) HIPC(hipStreamWaitEvent(L.compute, L.ev_comm_go, 0));
+    NBC(force_pass(ev.e[2], ev.e[3]));                       // pass B
+    from = ev.e[4];
+  } else NBC(comm_step());
   NBC(sync_all());
   float ms = 0.f;
-  HIPC(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
+  HIPC(hipEventElapsedTime(&ms, from, ev.e[1]));
   if (comm_ms) *comm_ms = ms;
   if (force_ms) {
     *force_ms = 0.0;
@@ -1332,7 +1386,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_TIMING: g.opt.timing = value ? 1 : 0; break;
     case NBODY_OPT_COMM: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.comm = value; break;
     case NBODY_OPT_OVERLAP: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.overlap = value; break;
-    case NBODY_OPT_GRAPH: g.opt.graph = value ? 1 : 0; break;
+    case NBODY_OPT_GRAPH: if (value < 0 || value > 256) return NBODY_ERR_ARG; g.opt.graph = value; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
     case NBODY_OPT_ISA_PHASE:
       if (value < 0 || value > 18) return NBODY_ERR_ARG;
@@ -1341,7 +1395,7 @@ int nbody_set_option(int key, int value) {
       if (isa_phase_is_diag(value) && !(g.init && g.fp64 && value == 2)) return NBODY_ERR_UNSUPPORTED;
 #endif
       g.opt.isa_phase = value; break;
-    case NBODY_OPT_WSPLIT: if (value != -1 && value != 1 && value != 4) return NBODY_ERR_ARG; g.opt.wsplit = value; break;
+    case NBODY_OPT_WSPLIT: if (value != -1 && value != 1 && value != 4 && value != 16) return NBODY_ERR_ARG; g.opt.wsplit = value; break;
     default: return NBODY_ERR_ARG;
   }
   if (g.init) { NBC(sync_all()); drop_step_graph(); return reconfigure(); }

@@ -45,6 +45,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;            // 4 waves, one per SIMD
+// threads of a workgroup whose WS waves share 64 rows and split the segment (ForceArgs::wsplit): 256 (WS = 1 or 4), 1024 (16)
+constexpr int wg_threads(int WS) { return WS > 1 ? 64 * WS : kBlock; }
 constexpr uint32_t kSoftBits = 0x3089705Fu;  // S/dzsoft.vhd:177
 
 // Address space 4 = constant: a load through it with a wave-uniform address is
@@ -79,7 +81,10 @@ struct ForceArgs {
   int wsplit;           // 1: a workgroup owns 256*R rows and its four waves walk the same segment for different rows;
                         // 4: a workgroup owns 64 rows and wave w walks piece w of 4 of the segment for those same rows — the four
                         //    sums are added through LDS in ascending source order (a third level of the sum), so a launch of
-                        //    the same workgroup count has a quarter of the global partial sums, tickets and last-arriver rounds
+                        //    the same workgroup count has a quarter of the global partial sums, tickets and last-arriver rounds;
+                        // 16: the same with workgroups of 16 waves (1024 threads): with one segment per slice a workgroup walks
+                        //    ALL sources of its 64 rows and finishes them itself — no global partial sums at all (mid N, where
+                        //    the sources fit an XCD's L2)
   int part_stride;      // words between two segments' rows in `partial`: row_count rounded up to 64, so that the 1 KiB (2 KiB in
                         // fp64) regions of different waves/workgroups never share a cache line
   float dt;
@@ -348,10 +353,19 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
     if (wave > 0) { V4 o = {s.bx[0], s.by[0], s.bz[0], (T)0}; ws[wave - 1][lane] = o; }
     __syncthreads();
     if (wave > 0) return;
+    // ascending source order: piece 1, 2, 3, ... onto piece 0; three LDS reads in flight at a time (all fifteen of a
+    // 16-wave workgroup at once would cost the kernel its 64-VGPR budget: the next chunk's address is made to depend on
+    // this chunk's sum, which is the only ordering the scheduler respects here)
+    int ln = lane;
 #pragma unroll
-    for (int k = 0; k < WS - 1; ++k) {     // ascending source order: piece 1, 2, 3 onto piece 0
-      const V4 p = ws[k][lane];
-      s.bx[0] = s.bx[0] + p.x; s.by[0] = s.by[0] + p.y; s.bz[0] = s.bz[0] + p.z;
+    for (int k0 = 0; k0 < WS - 1; k0 += 3) {
+      V4 p[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) if (k0 + k < WS - 1) p[k] = ws[k0 + k][ln];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k0 + k < WS - 1) { s.bx[0] = s.bx[0] + p[k].x; s.by[0] = s.by[0] + p[k].y; s.bz[0] = s.bz[0] + p[k].z; }
+      if constexpr (WS > 4) asm volatile("" : "+v"(ln) : "v"(s.bx[0]), "v"(s.by[0]), "v"(s.bz[0]));
     }
   }
   const NB_CONST ForceArgs* ka = (const NB_CONST ForceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -497,7 +511,7 @@ __device__ __forceinline__ void wave_work(const ForceArgs& a, int* seg, int* jb,
 // operands: no LDS traffic, no barrier, no VALU instruction spent on the
 // broadcast.  Groups are double-buffered by hand (load group g+1, compute g).
 template <int R, int ARITH, int WS>
-__global__ void __launch_bounds__(kBlock) force_smem_f32(ForceArgs a) {
+__global__ void __launch_bounds__(wg_threads(WS)) force_smem_f32(ForceArgs a) {
   NB_WS_LDS(f4, WS);
   int seg, jb, je, lane_row;
   wave_work<R, WS>(a, &seg, &jb, &je, &lane_row);
@@ -597,42 +611,42 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_s
     // and TIMING-ONLY forms with WRONG RESULTS (3..8, 14, 15) that price one part of the loop inside the real kernel
     // (tools/gen_force_loop.py, profiles/r02_loop_diagnostics.md).  The product library does not contain them.
     } else if constexpr (PLACEMENT == 2) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V2, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V2, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 3) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V3, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V3, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 4) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V4, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V4, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 5) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V5, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V5, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 6) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V6, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V6, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 7) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V7, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V7, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 8) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V8, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V8, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 9) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V9, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V9, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 10) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V10, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V10, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 11) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V11, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V11, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 12) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V12, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V12, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 13) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V13, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V13, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 14) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V14, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V14, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 15) {
       __shared__ f4 diag_tile[64];
       if (threadIdx.x < 64) diag_tile[threadIdx.x] = me[0];
       __syncthreads();
-      NB_RUN_LOOP(NB_FORCE_LOOP_V15, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V15, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 16) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V16, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V16, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 17) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V17, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V17, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 18) {
-      NB_RUN_LOOP(NB_FORCE_LOOP_V18, NB_FORCE_LOOP_CLOBBERS);
+      NB_RUN_LOOP(NB_FORCE_LOOP_V18, NB_FORCE_LOOP_DIAG_CLOBBERS);
 #endif
     } else {
       static_assert(PLACEMENT == 1 || LONG, "this loop form exists in the diagnostic build only (make diag)");
@@ -655,9 +669,10 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_s
   finish_rows<float, f4, 1, WS, LONG ? 13 : 11>(seg, i, row_end, me, s, ws_sums);
 }
 template <int PLACEMENT, int WS>
-__global__ void __launch_bounds__(kBlock) force_isa_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<PLACEMENT, 0, WS>(a, ws_sums); }
+__global__ void __launch_bounds__(wg_threads(WS), WS == 16 ? 8 : 1)   // (threads, min waves per SIMD): two 16-wave workgroups per CU need <= 64 VGPRs
+force_isa_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<PLACEMENT, 0, WS>(a, ws_sums); }
 template <int WS>
-__global__ void __launch_bounds__(kBlock) force_isa_long_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<1, 1, WS>(a, ws_sums); }
+__global__ void __launch_bounds__(wg_threads(WS)) force_isa_long_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<1, 1, WS>(a, ws_sums); }
 
 // ---------------------------------------------------------------------------
 // LDS variant (the north_star's "source bodies tiled into LDS", tile = 256 by
@@ -838,7 +853,7 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
 // fp64 (BASELINE config 5).  SMEM delivery, R bodies per lane.  One sequential sum per segment (fp64 has 29 more
 // bits than the 1e-5 target needs; sum_block is ignored).
 template <int R, int WS>
-__global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
+__global__ void __launch_bounds__(wg_threads(WS)) force_smem_f64(ForceArgs a) {
   NB_WS_LDS(d4, WS);
   int seg, jb, je, lane_row;
   wave_work<R, WS>(a, &seg, &jb, &je, &lane_row);
@@ -874,7 +889,7 @@ __global__ void __launch_bounds__(kBlock) force_smem_f64(ForceArgs a) {
 // fp64 with the hand-scheduled loop (force_loop_gfx950.inc, NB_FORCE_LOOP_F64_*): one body per lane, 4 sources
 // per iteration, every instruction 8 bytes (v_rsq_f64 in its _e64 encoding).  Same bits as force_smem_f64<1>.
 template <int PLACEMENT, int WS>
-__global__ void __launch_bounds__(kBlock) force_isa_f64(ForceArgs a) {
+__global__ void __launch_bounds__(wg_threads(WS)) force_isa_f64(ForceArgs a) {
   NB_WS_LDS(d4, WS);
   int seg, jb, je, i;
   wave_work<1, WS>(a, &seg, &jb, &je, &i);

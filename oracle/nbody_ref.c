@@ -157,8 +157,11 @@ DEFINE_SEQ_KERNEL(seq_fma_div, REF_D2_FMA3, REF_RSQRT_DIVSQRT)
  *   i.e. partial[(n_src + t) mod 16]; slots with no item hold 0 (:177-181).
  * S/compute_store.vhd:139-173 feeds results(0..15) of one axis to the tree;
  * S/final_adder.vhd:88-104 sums them pairwise.
- * (The exact cycle alignment of the latch cannot be checked without the IP's
- *  simulation model; the rotation by n_src mod 16 is this restatement's reading.) */
+ * The rotation by n_src mod 16 is not taken on trust: tests/test_fpga_scatter_model.py simulates the control logic of
+ * S/fxyz.vhd:129-184 cycle by cycle (FLUSH_CNT, the feedback mux, SCTTR_CNT, VALID_FMA_PREV, the results latch; the fma IP
+ * as the 16-stage pipeline S/top_level.vhd:40 says it is) for streams of 1..257 items and finds results(t) = the final
+ * value of partial (n_src + t) mod 16, zero where no item exists; the same model with this file's arithmetic plus the
+ * tree reproduces fpga16_f32() bit for bit. */
 static void fpga16_f32(const float *rows, int n_rows, const float *src, int n_src, float *acc, int d2_mode,
                        int rsqrt_mode) {
   const float soft = bits_to_float(REF_SOFT_BITS);

@@ -174,12 +174,13 @@ def make(name, n, seed, steps, nslices, sub, block, wsplit=1):
 
 if __name__ == "__main__":
     import sys
-    if len(sys.argv) > 1 and sys.argv[1] == "wsplit":   # only the fixtures of the wave-split order (the others are unchanged)
-        make("system_n560_wsplit4.json", 560, 5, 2, 1, 2, 64, wsplit=4)   # 2 segments of 280 = 4 pieces of 70: a block fold + 6 in each
-        make("system_n90_wsplit4_sharded.json", 90, 3, 3, 3, 2, 64, wsplit=4)  # 3 rank slices x 2 segments of 15 = pieces of 4,4,4,3
-        sys.exit(0)
-    make("system_n64_seq.json", 64, 42, 10, 1, 1, 0)           # the plain sequential sum, 10 steps (BASELINE config 1's loop, tiny)
-    make("system_n200_blocked.json", 200, 7, 3, 1, 3, 64)      # 3 segments of 67/67/66 sources, blocks of 64 + a remainder
-    make("system_n150_sharded.json", 150, 9, 2, 4, 2, 64)      # 4 rank slices (38/38/37/37) x 2 pieces: the multi-GPU order
-    make("system_n560_wsplit4.json", 560, 5, 2, 1, 2, 64, wsplit=4)
-    make("system_n90_wsplit4_sharded.json", 90, 3, 3, 3, 2, 64, wsplit=4)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # "wsplit" / "wsplit16": only those fixtures (the others are unchanged)
+    if which == "all":
+        make("system_n64_seq.json", 64, 42, 10, 1, 1, 0)           # the plain sequential sum, 10 steps (BASELINE config 1's loop, tiny)
+        make("system_n200_blocked.json", 200, 7, 3, 1, 3, 64)      # 3 segments of 67/67/66 sources, blocks of 64 + a remainder
+        make("system_n150_sharded.json", 150, 9, 2, 4, 2, 64)      # 4 rank slices (38/38/37/37) x 2 pieces: the multi-GPU order
+    if which in ("all", "wsplit"):
+        make("system_n560_wsplit4.json", 560, 5, 2, 1, 2, 64, wsplit=4)        # 2 segments of 280 = 4 pieces of 70: a block fold + 6 in each
+        make("system_n90_wsplit4_sharded.json", 90, 3, 3, 3, 2, 64, wsplit=4)  # 3 rank slices x 2 segments of 15 = pieces of 4, 4, 4, 3
+    if which in ("all", "wsplit16"):
+        make("system_n130_wsplit16.json", 130, 2, 2, 1, 1, 64, wsplit=16)      # one segment, 16 pieces: 14 of 9 sources, one of 4, one empty

@@ -54,3 +54,58 @@ def test_error_codes_and_recovery(nb):
         lib.nbody_shutdown()
     assert lib.nbody_sync() == L.ERR_NOT_INIT
     lib.nbody_shutdown()                                           # idempotent
+
+
+def test_a_failed_step_does_not_poison_the_next_one(nb):
+    """A multi-rank step that fails after its own-slice launch has run (here: the host transport's exchange callback fails
+    once) leaves the arrival counters of the in-launch combine part-counted; the library must re-zero them, or the next step
+    would combine before all partial sums are written.  Rank 0 of a two-rank job in this one process, the other rank's
+    positions supplied by the callback from a one-GPU run with the same segmentation: after the failure, the retried step
+    gives that run's bits."""
+    import ctypes as C
+    n, dt, jsub = 20000, 0.01, 4
+    pos, vel = nb.make_bodies(n, seed=15)
+    ref = nb.NBody(n)
+    ref.set_option(nb.OPT_JSLICES, 2)
+    ref.set_option(nb.OPT_JSUB, jsub)
+    ref.set_option(nb.OPT_FUSE_COMBINE, 1)
+    ref.upload(pos, vel)
+    ref.step(dt, 1)
+    p1, _ = ref.download()
+    ref.step(dt, 1)
+    p2, v2 = ref.download()
+    ref.close()
+    state = {"fail": False, "calls": 0}
+
+    def gather(host_ptr, n_total, word_bytes, rank, nranks):
+        state["calls"] += 1
+        if state["fail"]:
+            return 1
+        buf = np.ctypeslib.as_array((C.c_float * (n_total * 4)).from_address(host_ptr)).reshape(n_total, 4)
+        buf[n_total // 2:] = p1[n_total // 2:]          # rank 1's slice of the positions after step 1
+        return 0
+
+    eng = nb.NBody(n, rank=0, nranks=2, uid=None)
+    try:
+        eng.set_host_gather(gather)
+        eng.set_option(nb.OPT_JSUB, jsub)
+        eng.set_option(nb.OPT_FUSE_COMBINE, 1)
+        eng.set_option(nb.OPT_OVERLAP, 1)
+        assert eng.config["launches_per_step"] == 2 and eng.config["nseg"] == 2 * jsub
+        eng.upload(pos, vel)
+        eng.step(dt, 1)                  # every slice present after the upload: no exchange yet
+        eng.sync()
+        state["fail"] = True
+        with pytest.raises(nb.NBodyError):
+            eng.step(dt, 1)              # own-slice launch enqueued, then the exchange fails
+        eng.sync()
+        assert state["calls"] == 1
+        state["fail"] = False
+        eng.step(dt, 1)                  # the same step again
+        eng.sync()
+        gp, gv = eng.download_slice()
+        half = n // 2
+        assert np.array_equal(gp.view(np.uint32), p2[:half].view(np.uint32))
+        assert np.array_equal(gv.view(np.uint32), v2[:half].view(np.uint32))
+    finally:
+        eng.close()

@@ -81,3 +81,22 @@ def test_two_processes_one_gpu_host_transport(nb, tmp_path, world, overlap):
     assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
     assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32))
     assert np.array_equal(np.load(out + "_force.npy").view(np.uint32), wf.view(np.uint32))
+
+
+def test_bench_launches_and_supervises_its_own_workers(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts two fresh worker processes (it never touches the GPU
+    itself), both share this box's one GPU, RCCL refuses a second rank on the same device and the job runs on the host
+    transport — one JSON line with n_gpus 2, roofline, cpu_baseline, the transport used and the exposed communication."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NBODY_OVERSUBSCRIBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "262144", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["finite"]
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
+    assert "host-staged" in out["config"]["comm"] or "rccl" in out["config"]["comm"]
+    assert out["comm_exposed_ms_per_step"] >= 0 and out["config"]["kernel"]["nranks"] == 2

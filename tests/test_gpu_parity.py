@@ -215,6 +215,47 @@ def test_wave_split_third_level_bit_exact(nb, oracle_fast, engine_factory):
             assert not np.array_equal(bits(a), bits(b)) and row_rel(a, b).max() < 1e-5
 
 
+def test_diagnostic_library_encodings_are_bit_identical(nb, tmp_path):
+    """`make diag` (libnbody_hip_diag.so, -DNBODY_DIAG_LOOPS): the experiment encodings of the hand-scheduled loop (2 staggered
+    loads, 9..13 32-bit encodings, 12 round 1's loop, 16 v_subrev, 17 packed subtraction, 18 eps from a VGPR) run the same
+    operations in the same order as the product loop — same bits, with and without the wave split.  Skipped when the
+    diagnostic library has not been built (it is not part of the product build)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mini-nbody_amd", "libnbody_hip_diag.so")
+    if not os.path.exists(lib):
+        pytest.skip("libnbody_hip_diag.so not built (make diag)")
+    script = tmp_path / "diag.py"
+    script.write_text("""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+nb = importlib.import_module("mini-nbody_amd")
+n = 4096 + 37
+pos, _ = nb.make_bodies(n, seed=11)
+eng = nb.NBody(n)
+assert eng.info(nb._lib.INFO_DIAG_BUILD) == 1
+for ws in (1, 4):
+    eng.set_option(nb.OPT_WSPLIT, ws)
+    for jsub in (1, 3):
+        eng.set_option(nb.OPT_JSUB, jsub)
+        eng.set_option(nb.OPT_ISA_PHASE, 1)
+        ref = eng.forces(pos)
+        for phase in (0, 2, 9, 10, 11, 12, 13, 16, 17, 18):
+            eng.set_option(nb.OPT_ISA_PHASE, phase)
+            assert eng.config["variant"] == "isa" and eng.config["isa_phase"] == phase
+            assert np.array_equal(eng.forces(pos).view(np.uint32), ref.view(np.uint32)), (ws, jsub, phase)
+for phase in (3, 4, 5, 6, 7, 8, 14, 15):      # the timing-only forms are accepted here (and compute garbage)
+    eng.set_option(nb.OPT_ISA_PHASE, phase)
+eng.close()
+print("diag ok")
+""" % root)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NBODY_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "diag ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_diagnostic_loop_forms_are_not_in_the_product_library(nb, engine_factory):
     """NBODY_OPT_ISA_PHASE 2..18 (experiment encodings; 3..8, 14, 15 are timing-only forms with WRONG results) exist only in
     the diagnostic build (make diag): the product library refuses them and keeps running the product loop."""
@@ -931,6 +972,17 @@ def test_rccl_calls_on_a_one_rank_communicator(nb, engine_factory):
         eng.set_option(nb.OPT_COMM, comm)
         moved = eng.comm_selftest()
         assert moved == (n // 2) * 16            # one rank: the all-gather moves nothing, the ring step half the array
+    # the P > 1 transfer plans (offsets, byte counts, send/receive pairing; ragged slices: n = 10003) of 2, 3, 5 and 8 virtual
+    # ranks through real ncclSend/ncclRecv: afterwards every virtual rank's array holds all N words
+    for vp in (2, 3, 5, 8):
+        for form in (nb.COMM_RING, nb.COMM_DIRECT):
+            assert eng.comm_selftest_virtual(vp, form) == (vp - 1) * n * 16, (vp, form)
+    with pytest.raises(nb.NBodyError):
+        eng.comm_selftest_virtual(8, nb.COMM_ALLGATHER)      # a collective has no plan
+    # one ring step timed beside a force pass (tools/comm_probe.py makes the table of profiles/r03_comm_under_load.md)
+    for when in (0, 1, 2):
+        c_ms, f_ms = eng.comm_probe(64 << 10, when)
+        assert c_ms > 0 and (f_ms > 0) == (when != 0)
     # the context computes as usual
     pos, vel = nb.make_bodies(n, seed=1)
     eng.upload(pos, vel)

@@ -22,7 +22,7 @@ def measure(n, reps, sizes):
     prio = eng.info(nb._lib.INFO_COMM_PRIORITY)
     rows = []
     for nbytes in sizes:
-        for when in (0, 1, 2):
+        for when in (0, 1, 2, 3, 4):
             eng.comm_probe(nbytes, when)          # warm (RCCL channel set-up, kernels loaded)
             c, f = zip(*[eng.comm_probe(nbytes, when) for _ in range(reps)])
             rows.append((prio, nbytes, when, min(c), sorted(c)[len(c) // 2], max(c), sorted(f)[len(f) // 2]))
@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
-    sizes = [2 << 20, 7 << 20]     # one rank's slice at N = 1M, P = 8 (2 MiB); about what a rank receives per step (14 MiB) / 2
+    sizes = [2 << 20]     # one rank's slice at N = 1M, P = 8 (2 MiB); about what a rank receives per step (14 MiB) / 2
     rows = measure(args.n, args.reps, sizes)
     if args.child:
         for r in rows:
@@ -48,7 +48,9 @@ def main():
     for l in out.stdout.splitlines():
         if l.startswith("ROW "):
             rows.append(tuple(eval(x) for x in l[4:].split()))
-    names = {0: "alone (idle chip)", 1: "enqueued just BEFORE the force pass", 2: "enqueued just AFTER the force pass"}
+    names = {0: "alone (idle chip)", 1: "enqueued just BEFORE the force pass", 2: "enqueued just AFTER the force pass",
+             3: "steady state: released together with the next force pass by the previous one's end (ms from that end)",
+             4: "steady state + hand-shake: the next force pass waits until the transfer stream has reached its RCCL kernel"}
     print("| transfer stream priority | bytes | when | ring step min / median / max (ms, enqueue -> done) | force pass beside it (ms) |")
     print("|---|---|---|---|---|")
     for prio, nbytes, when, lo, med, hi, f in rows:

@@ -221,6 +221,11 @@ def build(pad, m=SHORT, stagger=False, diag=None, style="fmaak"):
     px, py, pz = DSETS[1]
     nb = m["bodies"]
     buf_bytes = 16 * nb
+    if style == "fmaak" and not diag and m is SHORT:
+        # the product loop reads eps as a literal, so EPS's SGPR (s33) is free inside the loop: the "full block" flag lives there
+        # and the loop's highest scalar is s71 (with a workgroup of 16 waves hipcc is told to fit 8 waves per SIMD and then
+        # treats s72 as reserved)
+        m = dict(m, full=int(EPS[1:]))
     ins = [
         "v_mov_b32 %s, %%[xi]" % XI, "v_mov_b32 %s, %%[yi]" % YI, "v_mov_b32 %s, %%[zi]" % ZI,
         "v_mov_b32 %s, %%[ax]" % AX, "v_mov_b32 %s, %%[ay]" % AY, "v_mov_b32 %s, %%[az]" % AZ,
@@ -437,7 +442,8 @@ def check(ins, strict=True):
 
 def main():
     regs = sorted(set([U] + T2 + [x for d in DSETS for x in d] + [int(r[1:]) for r in (XI, YI, ZI, AX, AY, AZ, BX, BY, BZ, EPSV)] + [40, 41, 42, 43, 44] + [PK_T, int(PK_AX[1:])] + [x for d in PK_DSETS for x in d]))
-    clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(PTR, FULL + 1)] + ["scc", "memory"]
+    clob = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(PTR, FULL)] + ["scc", "memory"]      # product loop: up to s71
+    clob_diag = ["v%d" % r for r in regs] + [EPS] + ["s%d" % r for r in range(PTR, FULL + 1)] + ["scc", "memory"]
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_force_loop.py — do not edit.  See that file for the why.\n")
         for v, pad in ((0, 14 - HEAD_BYTES // 4), (1, 15 - HEAD_BYTES // 4)):
@@ -446,6 +452,7 @@ def main():
             assert (head, phase) == ((56, 0) if v == 0 else (60, 4)), (head, phase)   # the placement round 1 measured
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
+        f.write("#define NB_FORCE_LOOP_DIAG_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob_diag))
         f.write("#define NB_FORCE_LOOP_GROUP %d\n" % GROUP)
         # Everything below up to NB_FORCE_LOOP_LONG exists only in the diagnostic build (`make diag`, -DNBODY_DIAG_LOOPS ->
         # libnbody_hip_diag.so): experiment encodings of the same operations (bit-identical, slower) and TIMING-ONLY forms

@@ -1,8 +1,12 @@
 #!/bin/bash
 # Cycles per wave-pair of the product loop and of its timing-only diagnostic forms (NBODY_OPT_ISA_PHASE 1, 3, 4, 5),
 # each under rocprofv3 --pmc GRBM_GUI_ACTIVE so that the clock each form actually runs at is known.
+# The diagnostic forms are not in the product library: `make diag` first (here, before gpurun: built .so files travel);
+# this script points the package at libnbody_hip_diag.so through NBODY_LIB.
 # usage: tools/profile_diag.sh  (on the GPU box; output gpurun_out/prof_diag/)
 set -u
+export NBODY_LIB="${NBODY_LIB:-$PWD/mini-nbody_amd/libnbody_hip_diag.so}"
+[ -f "$NBODY_LIB" ] || { echo "missing $NBODY_LIB: run make diag"; exit 1; }
 export PHASES="${PHASES:-1 3 4 5 2 0}"
 out=gpurun_out/prof_diag
 mkdir -p $out
