@@ -357,7 +357,7 @@ def main(argv=None):
                     help="HIP events around every force kernel inside the timed region (inline), or the timed region on the path "
                          "nbody_step() users get (HIP-graph replay, no events) and the kernel duration from a second pass (separate); "
                          "auto: separate when a step is short (one rank's share < 1e10 pairs), where events would change the path")
-    ap.add_argument("--deadline", type=float, default=420.0, help="N > 1: seconds a supervised attempt may take before it is killed and retried on the host transport")
+    ap.add_argument("--deadline", type=float, default=600.0, help="N > 1: seconds a supervised attempt may take before it is killed and retried on the host transport")
     args = ap.parse_args(argv)
     code = supervisor_main(args, argv)
     if code is not None:

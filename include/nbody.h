@@ -71,13 +71,14 @@ enum {
   NBODY_OPT_GRAPH = 12,    /* nbody_step on one GPU replays a captured HIP graph of an even number of steps: 1 (default) = 8 steps per graph
                               once a call brings 16, else 2; k >= 2 = k steps per graph; 0: launch every kernel */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
-  NBODY_OPT_WSPLIT = 17,   /* 4: a workgroup owns 64 bodies and its four waves walk a quarter of the source segment each; the four sums
-                              are added through LDS in ascending source order (a third level of the sum, like the reference's 16
-                              partial sums + adder tree, S/fxyz.vhd:129-145, S/final_adder.vhd:88-104).  Same workgroup count and
-                              walk per wave from a quarter of the global partial sums.  1: a workgroup owns 256 x IBLOCK bodies,
-                              every wave walks the whole segment (round 2's layout; the LDS / READLANE / FPGA16 kernels always).
-                              -1 (default): 4 wherever the kernel has it (SMEM and ISA deliveries, one body per lane), except with
-                              NBODY_SUM_SEQ in fp32, which means ONE sequential sum per segment. */
+  NBODY_OPT_WSPLIT = 17,   /* 4 / 16: a workgroup owns 64 bodies and its 4 / 16 waves walk one piece of the source segment each; the
+                              sums are added through LDS in ascending source order (a third level of the sum, like the reference's
+                              16 partial sums + adder tree, S/fxyz.vhd:129-145, S/final_adder.vhd:88-104).  Same number of waves and
+                              walk per wave from a quarter / a sixteenth of the global partial sums.  1: a workgroup owns
+                              256 x IBLOCK bodies, every wave walks the whole segment (round 2's layout; the LDS / READLANE / FPGA16
+                              kernels always).  -1 (default): where the kernel has it (SMEM and ISA deliveries, one body per lane),
+                              16 when a rank owns <= 8192 bodies (fp32), else 4; 1 with NBODY_SUM_SEQ in fp32, which means ONE
+                              sequential sum per segment. */
   NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: which generated form of the hand-scheduled loop runs (tools/gen_force_loop.py).
                               1 = the product loop (default); 0 = the same instructions placed one 4-byte phase off (-27 %, kept
                               so that the placement effect can be re-measured).  fp64: 1 = the product loop (VALU instructions at
@@ -119,7 +120,7 @@ enum { NBODY_INFO_N = 1, NBODY_INFO_N_LOCAL, NBODY_INFO_FIRST_BODY, NBODY_INFO_R
        NBODY_INFO_CU_COUNT, NBODY_INFO_CLOCK_KHZ, NBODY_INFO_FP64, NBODY_INFO_TILE, NBODY_INFO_STEPS_DONE,
        NBODY_INFO_SUM_ORDER, NBODY_INFO_SUM_BLOCK, NBODY_INFO_LAUNCHES_PER_STEP /* kernel launches one nbody_step() step takes */,
        NBODY_INFO_HAS_COMM /* 1: an RCCL communicator exists */,
-       NBODY_INFO_WSPLIT /* resolved NBODY_OPT_WSPLIT: 1 or 4 */, NBODY_INFO_ISA_PHASE, NBODY_INFO_LONG_BUFFERS /* option value, -1 = auto */,
+       NBODY_INFO_WSPLIT /* resolved NBODY_OPT_WSPLIT: 1, 4 or 16 */, NBODY_INFO_ISA_PHASE, NBODY_INFO_LONG_BUFFERS /* option value, -1 = auto */,
        NBODY_INFO_XCD_MAP /* option value, -1 = auto */, NBODY_INFO_FUSE_COMBINE /* resolved: 1 = in-launch combine */,
        NBODY_INFO_COMM_FORM /* resolved NBODY_COMM_* of a multi-rank context, -1 with one rank */,
        NBODY_INFO_COMM_PRIORITY /* HIP priority of the transfer stream (0 = default priority) */,

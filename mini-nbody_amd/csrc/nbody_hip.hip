@@ -178,7 +178,13 @@ void resolve_config() {
   // automatic: wherever it exists, except for NBODY_SUM_SEQ in fp32, whose meaning is ONE sequential sum per segment (what a CPU
   // nbody.c does); fp64 contexts, which always sum sequentially and have 29 bits to spare, take the split
   const bool auto_split = g.fp64 || g.opt.sum_order != NBODY_SUM_SEQ;
-  g.wsplit = !can_split ? 1 : (g.opt.wsplit == 4 || g.opt.wsplit == 16) ? g.opt.wsplit : (g.opt.wsplit < 0 && auto_split) ? 4 : 1;
+  // ... with 16 waves per workgroup where a rank's bodies fill at most half the CUs with 64-row workgroups (n_local <= 8192):
+  // there a step is latency and the 16-wave form needs the fewest global partial sums for the same number of waves (measured
+  // per step, profiles/r03_small_n.md: N = 2048 7.5 us against 9.1 with 4 waves, N = 4096 9.7 / 10.2, N = 8192 22.0 / 22.1; from
+  // N = 16384 up the two are level in fp32 and 4 waves win by 4 % in fp64, so 4 it is)
+  const int cus_ = g.cu_count > 0 ? g.cu_count : 256;
+  const int auto_ws = (!g.fp64 && (n_local + 63) / 64 <= cus_ / 2) ? 16 : 4;
+  g.wsplit = !can_split ? 1 : (g.opt.wsplit == 4 || g.opt.wsplit == 16) ? g.opt.wsplit : (g.opt.wsplit < 0 && auto_split) ? auto_ws : 1;
   if (g.wsplit == 16 && g.variant == NBODY_VARIANT_ISA && !g.fp64 && g.opt.isa_phase > 1) g.wsplit = 4;   // diagnostic loop forms: 4 waves
   // Small launches and large ones want different things (profiles/r02_small_n.md, one process, wall clock per step):
   //   large (even 64 segments give >= 16 workgroups per CU; N >= 16384 on one GPU): many short segments for load
@@ -208,7 +214,13 @@ void resolve_config() {
     const int mem_sub = (int)std::max(1LL, std::max(8LL, words_cap) / g.nslices);
     sub = std::min(sub, std::max(mem_sub, (target_blocks + blocks - 1) / blocks));
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
-    if (g.wsplit > 1) {
+    if (g.wsplit == 16) {
+      // 16-wave workgroups: about one workgroup per CU over the step's launches (N = 4096: 4 segments = 256 workgroups 9.7 us
+      // per step, 2: 13.6, 8: 11.9; N = 2048: 4: 7.5, 2: 9.5; N = 8192: 2: 22.0, 4: 23.2, 1: 36.6), pieces of >= 32 sources
+      const int blocks64 = (n_local + 63) / 64;
+      sub = std::max(1, (cus / g.nslices + blocks64 - 1) / std::max(1, blocks64));
+      sub = std::max(1, std::min(sub, slice_len / 512));
+    } else if (g.wsplit > 1) {
       // With the wave split a workgroup has a quarter of the rows and its waves a quarter of the segment each: the same
       // number of workgroups and the same walk per wave come from a QUARTER of the global segments (partial sums, tickets,
       // last-arriver rounds) — but not fewer than keep a segment inside one XCD's L2 share (2 MiB: N = 1M fp32 stays at 8,

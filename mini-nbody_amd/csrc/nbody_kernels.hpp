@@ -431,8 +431,13 @@ __device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, 
       if (sg0 + k < a.nseg) {
         char* base = (char*)a.partial + ((size_t)(sg0 + k) * a.part_stride + wg_rel0) * sizeof(V4);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, wg_rows * (int)sizeof(V4), 0x00020000);
+        if (sg0 + k == seg) {   // (wave-uniform) this wave's own partial sum is still in its registers: not read back
 #pragma unroll
-        for (int r = 0; r < R; ++r) p[k][r] = load_word_sc1<V4>(rs, lane_off + r * kBlock * (int)sizeof(V4));
+          for (int r = 0; r < R; ++r) { V4 o = {s.bx[r], s.by[r], s.bz[r], (T)0}; p[k][r] = o; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) p[k][r] = load_word_sc1<V4>(rs, lane_off + r * kBlock * (int)sizeof(V4));
+        }
       }
     }
 #pragma unroll

@@ -7,7 +7,7 @@
  * §2: billion pair-interactions/s = N^2 * timed_steps / seconds / 1e9.
  *
  * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]
- *              [--sum seq|blocked] [--block K] [--one-launch | --two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4]
+ *              [--sum seq|blocked] [--block K] [--one-launch | --two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4|16]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--block") && a + 1 < argc) block = atoi(argv[++a]);
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4|16]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   const float dt = 0.01f;

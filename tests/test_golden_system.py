@@ -32,8 +32,9 @@ def bits(a):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 5
+    assert len(FIXTURES) >= 6
     assert sum(1 for f in FIXTURES if json.load(open(f))["order"].get("wsplit", 1) == 4) >= 2   # the wave-split order too
+    assert sum(1 for f in FIXTURES if json.load(open(f))["order"].get("wsplit", 1) == 16) >= 1  # and 16-wave workgroups
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
@@ -74,7 +75,7 @@ def test_engine_reproduces_the_fixture(nb, path):
         ws = o.get("wsplit", 1)
         eng.set_option(nb.OPT_WSPLIT, ws)
         # the wave-split order exists in the scalar-delivery kernel with one body per lane; the plain one in all of them
-        shapes = ((nb.VARIANT_SMEM, 1),) if ws == 4 else ((nb.VARIANT_SMEM, 1), (nb.VARIANT_SMEM, 4), (nb.VARIANT_LDS, 2), (nb.VARIANT_READLANE, 2))
+        shapes = ((nb.VARIANT_SMEM, 1),) if ws > 1 else ((nb.VARIANT_SMEM, 1), (nb.VARIANT_SMEM, 4), (nb.VARIANT_LDS, 2), (nb.VARIANT_READLANE, 2))
         for variant, iblock in shapes:
             for fuse in (1, 0):
                 eng.set_option(nb.OPT_VARIANT, variant)

@@ -68,6 +68,7 @@ def test_a_failed_step_does_not_poison_the_next_one(nb):
     ref = nb.NBody(n)
     ref.set_option(nb.OPT_JSLICES, 2)
     ref.set_option(nb.OPT_JSUB, jsub)
+    ref.set_option(nb.OPT_WSPLIT, 4)
     ref.set_option(nb.OPT_FUSE_COMBINE, 1)
     ref.upload(pos, vel)
     ref.step(dt, 1)
@@ -89,6 +90,7 @@ def test_a_failed_step_does_not_poison_the_next_one(nb):
     try:
         eng.set_host_gather(gather)
         eng.set_option(nb.OPT_JSUB, jsub)
+        eng.set_option(nb.OPT_WSPLIT, 4)
         eng.set_option(nb.OPT_FUSE_COMBINE, 1)
         eng.set_option(nb.OPT_OVERLAP, 1)
         assert eng.config["launches_per_step"] == 2 and eng.config["nseg"] == 2 * jsub

@@ -33,6 +33,8 @@ WORKER = textwrap.dedent("""
     p, v = eng.download()
     cfg = eng.config
     assert cfg["nranks"] == world and cfg["rank"] == rank
+    if rank == 0:
+        open({out!r} + "_wsplit.txt", "w").write(str(cfg["wsplit"]))
     if rank == world - 1:
         np.save({out!r} + "_force.npy", f)
     if rank == 0:
@@ -72,6 +74,9 @@ def test_two_processes_one_gpu_host_transport(nb, tmp_path, world, overlap):
     try:
         one.set_option(nb.OPT_JSUB, jsub)
         one.set_option(nb.OPT_JSLICES, world)
+        # the summation order of the P-rank job on one GPU: its slices, its pieces per slice, its waves per workgroup (the
+        # engine picks the last from a rank's body count, which differs between the job and this one-GPU restatement)
+        one.set_option(nb.OPT_WSPLIT, int(open(out + "_wsplit.txt").read()))
         wf = one.forces(pos)
         one.upload(pos, vel)
         one.step(0.01, steps)

@@ -181,11 +181,13 @@ def test_fast_variants_agree_bitwise_and_within_tolerance(nb, oracle_fast, engin
     assert np.all(ref[:, 3] == 0)   # S/compute_store.vhd:242: the 4th word is 0
 
 
-def test_wave_split_third_level_bit_exact(nb, oracle_fast, engine_factory):
-    """NBODY_OPT_WSPLIT = 4: a workgroup owns 64 rows, wave w walks piece w of the segment, the four sums are added through
-    LDS in ascending order.  Strict arithmetic against the oracle's order with wsplit = 4 (ref_order_t), bit for bit: ragged
-    sizes incl. segments shorter than four sources (empty pieces), several slices, both combine forms, block folds inside
-    pieces; and the forces differ from the wsplit = 1 order only by re-association (same values to 1e-6)."""
+@pytest.mark.parametrize("ws", [4, 16])
+def test_wave_split_third_level_bit_exact(nb, oracle_fast, engine_factory, ws):
+    """NBODY_OPT_WSPLIT = 4 / 16: a workgroup owns 64 rows, wave w walks piece w of the segment, the sums are added through
+    LDS in ascending order.  Strict arithmetic against the oracle's order with that wsplit (ref_order_t), bit for bit: ragged
+    sizes incl. segments shorter than the wave count (empty pieces), several slices, both combine forms, block folds inside
+    pieces; the hand-scheduled loop agrees with the compiled kernel; and the forces differ from the wsplit = 1 order only by
+    re-association."""
     for n in (1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, 6013):
         pos, vel = nb.make_bodies(n, seed=300 + n)
         eng = engine_factory(n)
@@ -194,9 +196,9 @@ def test_wave_split_third_level_bit_exact(nb, oracle_fast, engine_factory):
             if n < jsl:
                 continue
             for fuse in (1, 0):
-                set_variant(nb, eng, "smem", 1, jsub=jsub, jslices=jsl, arith=nb.ARITH_STRICT, wsplit=4)
+                set_variant(nb, eng, "smem", 1, jsub=jsub, jslices=jsl, arith=nb.ARITH_STRICT, wsplit=ws)
                 eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
-                assert eng.config["wsplit"] == 4 and eng.order["wsplit"] == 4
+                assert eng.config["wsplit"] == ws and eng.order["wsplit"] == ws
                 got = eng.forces(pos)
                 want = oracle_forces(oracle_fast, eng, pos)
                 assert np.array_equal(bits(got), bits(want)), (n, jsub, jsl, fuse)
@@ -206,13 +208,39 @@ def test_wave_split_third_level_bit_exact(nb, oracle_fast, engine_factory):
                 op, ov = pos.copy(), vel.copy()
                 oracle_step(oracle_fast, eng, op, ov, 0.01, 3)
                 assert np.array_equal(bits(gp), bits(op)) and np.array_equal(bits(gv), bits(ov)), (n, jsub, jsl, fuse)
+            # the timed arithmetic: hand-scheduled loop (both buffer lengths) == compiled kernel
+            out = []
+            for variant, long_buffers in (("smem", -1), ("isa", 0), ("isa", 1)):
+                set_variant(nb, eng, variant, 1 if variant == "smem" else 0, jsub=jsub, jslices=jsl, arith=nb.ARITH_FMA3, wsplit=ws)
+                eng.set_option(nb.OPT_ISA_LONG_BUFFERS, long_buffers)
+                assert eng.config["wsplit"] == ws
+                eng.upload(pos, vel)
+                eng.step(0.01, 2)
+                out.append((eng.forces(pos),) + eng.download())
+            for o in out[1:]:
+                for x, y in zip(o, out[0]):
+                    assert np.array_equal(bits(x), bits(y)), (n, jsub, jsl)
+            eng.set_option(nb.OPT_ISA_LONG_BUFFERS, -1)
         if n >= 1000:
-            set_variant(nb, eng, "smem", 1, jsub=2, arith=nb.ARITH_STRICT, wsplit=4)
+            set_variant(nb, eng, "smem", 1, jsub=2, arith=nb.ARITH_STRICT, wsplit=ws)
             a = eng.forces(pos)
             set_variant(nb, eng, "smem", 1, jsub=2, arith=nb.ARITH_STRICT, wsplit=1)
             assert eng.order["wsplit"] == 1
             b = eng.forces(pos)
             assert not np.array_equal(bits(a), bits(b)) and row_rel(a, b).max() < 1e-5
+    # fp64: the same layouts, hand-scheduled loop == compiled kernel, and both within fp64 tolerance of the oracle
+    n = 3001
+    pos, vel = nb.make_bodies(n, seed=9, dtype=np.float64)
+    eng = engine_factory(n, fp64=True)
+    eng.set_option(nb.OPT_WSPLIT, ws)
+    eng.set_option(nb.OPT_JSUB, 2)
+    assert eng.config["wsplit"] == ws and eng.config["variant"] == "isa"
+    a = eng.forces(pos)
+    eng.set_option(nb.OPT_VARIANT, nb.VARIANT_SMEM)
+    eng.set_option(nb.OPT_IBLOCK, 1)
+    assert eng.config["wsplit"] == ws and eng.config["variant"] == "smem"
+    assert np.array_equal(bits(a), bits(eng.forces(pos)))
+    assert maxnorm_rel(a, oracle_fast.forces_f64(pos)) < 1e-13
 
 
 def test_diagnostic_library_encodings_are_bit_identical(nb, tmp_path):
@@ -237,13 +265,15 @@ n = 4096 + 37
 pos, _ = nb.make_bodies(n, seed=11)
 eng = nb.NBody(n)
 assert eng.info(nb._lib.INFO_DIAG_BUILD) == 1
-for ws in (1, 4):
+for ws in (1, 4, 16):
     eng.set_option(nb.OPT_WSPLIT, ws)
     for jsub in (1, 3):
         eng.set_option(nb.OPT_JSUB, jsub)
         eng.set_option(nb.OPT_ISA_PHASE, 1)
         ref = eng.forces(pos)
-        for phase in (0, 2, 9, 10, 11, 12, 13, 16, 17, 18):
+        # (16-wave workgroups exist for the product loop and its placement twin; the other forms would run with 4 waves,
+        #  which is another summation order)
+        for phase in ((0,) if ws == 16 else (0, 2, 9, 10, 11, 12, 13, 16, 17, 18)):
             eng.set_option(nb.OPT_ISA_PHASE, phase)
             assert eng.config["variant"] == "isa" and eng.config["isa_phase"] == phase
             assert np.array_equal(eng.forces(pos).view(np.uint32), ref.view(np.uint32)), (ws, jsub, phase)
@@ -640,6 +670,7 @@ def test_config4_workload_eight_virtual_ranks(nb, oracle_fast, engine_factory, m
     one = engine_factory(n)
     one.set_option(nb.OPT_JSLICES, P)
     one.set_option(nb.OPT_JSUB, cfg["jsub"])
+    one.set_option(nb.OPT_WSPLIT, cfg["wsplit"])
     assert one.config["nseg"] == cfg["nseg"]
     one.upload(pos, vel)
     one.step(dt, steps)
@@ -877,6 +908,7 @@ def test_virtual_multi_gpu_schedule_bitwise(nb, oracle_fast, engine_factory, mon
         one.set_option(nb.OPT_IBLOCK, 2)
         one.set_option(nb.OPT_JSUB, 2)
         one.set_option(nb.OPT_JSLICES, P)
+        one.set_option(nb.OPT_WSPLIT, 4)      # (the engine's own choice depends on a rank's body count: pinned on both sides)
         one.upload(pos, vel)
         one.step(dt, steps)
         wp, wv = one.download()
@@ -893,6 +925,7 @@ def test_virtual_multi_gpu_schedule_bitwise(nb, oracle_fast, engine_factory, mon
             eng = engine_factory(n, ngpus=P)
             eng.set_option(nb.OPT_IBLOCK, 2)
             eng.set_option(nb.OPT_JSUB, 2)
+            eng.set_option(nb.OPT_WSPLIT, 4)
             eng.set_option(nb.OPT_OVERLAP, overlap)
             eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
             eng.upload(pos, vel)
@@ -913,6 +946,7 @@ def test_virtual_eight_ranks_all_entry_points(nb, engine_factory, monkeypatch, f
 
     def run(eng):
         eng.set_option(nb.OPT_JSUB, 2)
+        eng.set_option(nb.OPT_WSPLIT, 16 if not fp64 else 4)
         out = {}
         out["forces"] = eng.forces(pos)
         p, v = pos.copy(), vel.copy()
