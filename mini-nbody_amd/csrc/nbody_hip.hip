@@ -6,8 +6,8 @@
 //   pos[2]   2 x N words      full position set, double-buffered: a step reads pos[cur] and writes the
 //                             rank's slice of pos[cur^1]; the other slices of pos[cur^1] arrive over xGMI
 //   vel      n_local words    never leaves the rank
-//   partial  nseg x n_local   per-source-segment partial forces (unused when nseg == 1)
-//   tickets  4 per 256 rows   arrival counters (one per wave) of the in-launch combine (zero between steps)
+//   partial  nseg x rows'     per-source-segment partial forces (unused when nseg == 1); rows' = the launch's rows rounded up to 64
+//   tickets  1 per 64 rows    arrival counters of the in-launch combine (zero between steps)
 //   force    n_local words    last combined forces (mailbox / parity entry points)
 // word = {x,y,z,w}: 16 B (fp32) or 32 B (fp64) — the reference's RAM word, S/top_level.vhd:206-208.
 //
@@ -16,10 +16,10 @@
 // pieces); a step first runs on the rank's own slice while the other slices
 // travel (ring of ncclSend/ncclRecv on a second stream, or peer copies when one
 // process drives all GPUs), then on the arrived slices.  Partial sums are kept
-// per segment and combined in ascending source order — by the last workgroup to
-// arrive for a block of rows, inside the force launch (finish_rows in
-// nbody_kernels.hpp) — so the result is bit-identical for every arrival order
-// and for a single GPU configured with the same segmentation.
+// per segment and combined in ascending source order — by the last 64-row unit to
+// arrive, inside the force launch (finish_rows in nbody_kernels.hpp) — so the
+// result is bit-identical for every arrival order and for a single GPU configured
+// with the same segmentation (NBODY_OPT_JSLICES, _JSUB, _WSPLIT).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types only; the library is resolved with dlopen when nranks > 1
 #include <dlfcn.h>
@@ -208,9 +208,9 @@ void resolve_config() {
     int slice_len = g.n / g.nslices;
     int max_sub = std::max(1, slice_len / 128);    // keep >= 128 sources per segment (a wave walks its segment serially)
     sub = std::max(sub, (slice_len + 131071) / 131072);   // and <= 131072 sources (a workgroup's lifetime: the launch's tail)
-    // ... unless the partial sums (nseg words per body) would then exceed 1 GiB per rank: at that size (N >= 8M fp32,
-    // 4M fp64) a workgroup's lifetime is a negligible part of a step of many seconds anyway; never below 8 segments a step
-    const long long words_cap = (1LL << 30) / (long long)word_bytes() / n_local;
+    // ... unless the partial sums (nseg words per body) would then exceed 16 GiB per rank (288 GB are there to be used): at that
+    // size (N >= 32M fp32, 16M fp64) a workgroup's lifetime is a negligible part of a step of minutes anyway; never below 8 segments
+    const long long words_cap = (16LL << 30) / (long long)word_bytes() / n_local;
     const int mem_sub = (int)std::max(1LL, std::max(8LL, words_cap) / g.nslices);
     sub = std::min(sub, std::max(mem_sub, (target_blocks + blocks - 1) / blocks));
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
@@ -223,11 +223,16 @@ void resolve_config() {
     } else if (g.wsplit > 1) {
       // With the wave split a workgroup has a quarter of the rows and its waves a quarter of the segment each: the same
       // number of workgroups and the same walk per wave come from a QUARTER of the global segments (partial sums, tickets,
-      // last-arriver rounds) — but not fewer than keep a segment inside one XCD's L2 share (2 MiB: N = 1M fp32 stays at 8,
-      // one per XCD, each fetched once; four waves walking four quarters of an 8 MiB segment would stream it per resident set)
+      // last-arriver rounds).  Two corrections, both measured (profiles/r03_traffic_wsplit.md, r03_sweep_segments_*.txt):
+      //  - never fewer segments than keep one inside an XCD's L2 share (2 MiB): N = 1M fp32 stays at 8, one per XCD, each
+      //    fetched once — with 4 the positions are re-fetched per resident set (+1.9 GB per step), with 2 every workgroup streams
+      //    its 8 MiB from the Infinity Cache (43 GB); N = 4M fp64 on one GPU: 64 segments instead of 8 (4.9 TB per step);
+      //  - a P-rank job halves instead of quartering: its launches are P times smaller and want the finer grain (8 virtual
+      //    ranks at N = 1M: 1 / 2 / 4 segments per slice 4631 / 4643 / 4661 G pairs/s, one rank 4660)
       const long long slice_bytes = (long long)slice_len * (long long)word_bytes();
-      const int l2_sub = (int)((slice_bytes + (2LL << 20) - 1) / (2LL << 20));
-      sub = std::max((sub + g.wsplit - 1) / g.wsplit, std::min(sub, l2_sub));
+      const int l2_sub = (int)std::min<long long>(std::min(64, std::max(1, mem_sub)), (slice_bytes + (2LL << 20) - 1) / (2LL << 20));
+      const int div = g.nslices > 1 ? 2 : g.wsplit;
+      sub = std::max((sub + div - 1) / div, l2_sub);
     }
   }
   g.sub = sub;

@@ -31,10 +31,15 @@
 // 3e-7 (profiles/r02_error_budget.md).  Cost: 3 v_add + 7 v_mov per 12288 VALU instructions.  K = 0 keeps the plain
 // sequential sum (study mode; what a CPU nbody.c does).
 //
+// Who walks what (ForceArgs::wsplit, round 3): a workgroup owns 64 rows and its 4 or 16 waves walk one piece of the segment
+// each for those same rows; the piece sums are joined through LDS in ascending source order — a third level of the sum —
+// so the same waves need a quarter (a sixteenth) of the global partial sums.  wsplit = 1 is round 2's layout (256*R rows per
+// workgroup, every wave walks the whole segment), which the LDS, READLANE and FPGA-order kernels keep.
+//
 // How a row's force is finished (ForceArgs::finish): with one segment the kernel applies kick and drift itself;
-// with several, every wave stores its partial sums and the LAST wave to arrive for its rows (an agent-scope ticket
-// per wave of a row block) adds the partials in ascending segment order and applies kick and drift — one launch per
-// step, and the result does not depend on which wave came last; or (small launches) a combine kernel does, same bits.
+// with several, every 64-row unit stores its partial sums and the LAST to arrive for its rows (an agent-scope ticket
+// per 64 rows) adds the partials in ascending segment order and applies kick and drift — one launch per
+// step, and the result does not depend on who came last; or (small launches) a combine kernel does, same bits.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -571,7 +576,7 @@ __global__ void __launch_bounds__(wg_threads(WS)) force_smem_f32(ForceArgs a) {
 // (small N), where a 4-body buffer's 48 instructions no longer cover the ~280 ns of a scalar load.
 #include "force_loop_gfx950.inc"
 // SGPR budgets: 81-96 SGPRs leave room for 7 waves per SIMD, <= 80 for 8 (MI355X_MICROARCH.md, "Occupancy API" row).  The
-// product loop's scalars end at s72 (79 with VCC etc.: 8 waves); the long-buffer loop holds 64 buffer SGPRs (106: 6 waves),
+// product loop's scalars end at s71 (78-79 with VCC etc.: 8 waves); the long-buffer loop holds 64 buffer SGPRs (106: 6-7 waves),
 // which is why it is a kernel of its own.
 template <int PLACEMENT, int LONG, int WS>
 __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_sums)[64]) {

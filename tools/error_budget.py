@@ -69,6 +69,11 @@ def main():
         row("CPU oracle, blocked 1024, 8 segments", ora.forces_order(sample, pos, summ=O.SUM_BLOCKED, sub=8))
         row("CPU oracle, blocked 1024, 8 x 8 segments (the 8-GPU order)", ora.forces_order(sample, pos, summ=O.SUM_BLOCKED, nslices=8, sub=8))
         row("CPU oracle, blocked 256, 8 segments", ora.forces_order(sample, pos, summ=O.SUM_BLOCKED, block=256, sub=8))
+        # round 3: the wave split adds a level — segments x pieces (4 or 16 waves of a workgroup), blocks inside a piece
+        row("CPU oracle, blocked 1024, 8 segments x 4 pieces (round 3's order at N = 1M)", ora.forces_order(sample, pos, summ=O.SUM_BLOCKED, sub=8, wsplit=4))
+        row("CPU oracle, blocked 1024, 16 segments x 4 pieces (N = 16384 ... 65536)", ora.forces_order(sample, pos, summ=O.SUM_BLOCKED, sub=16, wsplit=4))
+        row("CPU oracle, blocked 1024, 4 segments x 16 pieces (N <= 4096)", ora.forces_order(sample, pos, summ=O.SUM_BLOCKED, sub=4, wsplit=16))
+        row("CPU oracle, blocked 1024, 8 x 4 segments x 4 pieces (round 3's 8-GPU order at N = 1M)", ora.forces_order(sample, pos, summ=O.SUM_BLOCKED, nslices=8, sub=4, wsplit=4))
         if not use_gpu:
             continue
         eng = nb.NBody(n)
@@ -76,7 +81,7 @@ def main():
             eng.upload(pos, np.zeros_like(pos))
 
             def gpu(opts):
-                for k, v in ((nb.OPT_JSUB, 0), (nb.OPT_JSLICES, 1), (nb.OPT_SUM_ORDER, nb.SUM_BLOCKED), (nb.OPT_ARITH, nb.ARITH_FMA3)):
+                for k, v in ((nb.OPT_JSUB, 0), (nb.OPT_JSLICES, 1), (nb.OPT_SUM_ORDER, nb.SUM_BLOCKED), (nb.OPT_ARITH, nb.ARITH_FMA3), (nb.OPT_WSPLIT, -1)):
                     eng.set_option(k, v)
                 for k, v in opts.items():
                     eng.set_option(k, v)
@@ -84,7 +89,8 @@ def main():
 
             for name, opts in (
                 ("GPU timed mode (v_rsq_f32), DEFAULT configuration", {}),
-                ("GPU v_rsq_f32, blocked, 8 slices x 8 pieces (the 8-GPU order at N = 1M)", {nb.OPT_JSLICES: 8, nb.OPT_JSUB: 8}),
+                ("GPU v_rsq_f32, blocked, 8 slices x 4 segments x 4 pieces (the 8-GPU order at N = 1M)", {nb.OPT_JSLICES: 8, nb.OPT_JSUB: 4, nb.OPT_WSPLIT: 4}),
+                ("GPU v_rsq_f32, round 2's layout (every wave walks the whole segment), default segmentation", {nb.OPT_WSPLIT: 1}),
                 ("GPU v_rsq_f32, ONE sequential sum", {nb.OPT_JSUB: 1, nb.OPT_SUM_ORDER: nb.SUM_SEQ}),
                 ("GPU v_rsq_f32, sequential, default segmentation (round 1's timed path)", {nb.OPT_SUM_ORDER: nb.SUM_SEQ}),
                 ("GPU v_rsq_f32, FPGA order, 1 segment", {nb.OPT_JSUB: 1, nb.OPT_SUM_ORDER: nb.SUM_FPGA16}),
@@ -92,7 +98,7 @@ def main():
                 ("GPU strict, default configuration (== CPU oracle bitwise)", {nb.OPT_ARITH: nb.ARITH_STRICT}),
             ):
                 f = gpu(opts)
-                row(name + " [%d seg, %s]" % (eng.config["nseg"], eng.config["sum_order"]), f)
+                row(name + " [%d seg x %d pieces, %s]" % (eng.config["nseg"], eng.config["wsplit"], eng.config["sum_order"]), f)
         finally:
             eng.close()
 

@@ -25,7 +25,8 @@ profiles/r01_sweep_isa.txt):
 
 Loop shape (one wave, one body i per lane, sources delivered as wave-uniform scalar loads):
     A = s[36:51], B = s[52:67]: two buffers of 4 bodies {x,y,z,w}; pointer s[34:35], group counter s68, stride s69,
-    groups left s70, groups per block s71, full-block flag s72 (79 SGPRs with VCC etc.: 8 waves per SIMD fit)
+    groups left s70, groups per block s71, full-block flag s33 in the product loop (eps is a literal there; s72 in the forms
+    that keep eps in s33): 78-79 SGPRs with VCC etc., 8 waves per SIMD fit
     prologue: load A
     block: s68 = min(s70, s71) groups
       loop:  wait A | load B | 4 bodies from A (48 VALU) | advance pointer | wait B | load A (next group) | 4 bodies from B
@@ -54,7 +55,7 @@ T2 = [20, 24]                           # d2 / inv / inv3 (even), alternating wi
 DSETS = [(21, 23, 25), (27, 29, 31)]    # dx dy dz (odd), alternating with the body index
 XI, YI, ZI, AX, AY, AZ, EPS = "v8", "v9", "v10", "v12", "v13", "v14", "s33"
 A_BASE, B_BASE = 36, 52            # s_load_dwordx16 destinations: multiples of 4
-PTR, CNT, STRIDE = 34, 68, 69      # highest SGPR of the loop: s72 -> 79 SGPRs with VCC etc.: 8 waves per SIMD fit
+PTR, CNT, STRIDE = 34, 68, 69      # highest SGPR of the product loop: s71 (s72 in the diagnostic forms) -> 8 waves per SIMD fit
                                    # (81-96 SGPRs: 7, MI355X_MICROARCH.md "Occupancy API" row)
 GROUP = 8
 
