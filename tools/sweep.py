@@ -2,7 +2,7 @@
 """Kernel configuration sweep on one GPU: (variant, bodies per lane, source sub-segments) -> G pairs/s from the
 HIP-event time of the force kernels.  One process, interleaved rounds (cdna guide §5.4 rule 24).
 usage: python tools/sweep.py [--n N] [--steps K] [--rounds M] [--configs "smem:4:1,lds:2:4,isa1:1:8:0:sum=seq:fuse=0,..."]
-config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked][:blk=K][:fuse=0|1][:long=0|1][:xcd=-1|0|1][:ws=1|4|16][:graph=K][:jsl=P (source slices, as a P-rank job cuts them)]"""
+config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked][:blk=K][:fuse=0|1][:long=0|1][:xcd=-1|0|1][:ws=1|4|16][:graph=K][:jsl=P (source slices, as a P-rank job cuts them)][:arith=fma3|reference|strict|refstrict]"""
 import argparse
 import importlib
 import os
@@ -55,6 +55,8 @@ def main():
             eng.set_option(nb.OPT_WSPLIT, int(opts.get("ws", -1)))
             eng.set_option(nb.OPT_GRAPH, int(opts.get("graph", 1)))
             eng.set_option(nb.OPT_JSLICES, int(opts.get("jsl", 0)))
+            eng.set_option(nb.OPT_ARITH, {"fma3": nb.ARITH_FMA3, "reference": nb.ARITH_REFERENCE, "strict": nb.ARITH_STRICT,
+                                          "refstrict": nb.ARITH_REFERENCE_STRICT}[opts.get("arith", "fma3")])
             eng.set_option(nb.OPT_WAVES_PER_SIMD, w)
             eng.set_option(nb.OPT_VARIANT, vmap[v])
             eng.set_option(nb.OPT_ISA_PHASE, int(v[3:]) if v.startswith("isa") else 1)
