@@ -197,7 +197,11 @@ void resolve_config() {
   //     hand-off is exposed (N = 4096: 22.7 us, N = 8192: 36.4).
   const int cus = g.cu_count > 0 ? g.cu_count : 256;
   const int blocks = blocks_for(n_local, R, 1);   // in workgroups of 256*R rows: `sub` below counts pieces of a slice as round 2 did
-  const bool small = (long long)blocks * 64 < 16LL * cus;
+  // "small" = the latency regime: fp32: where the 16-wave workgroups are the automatic choice (n_local <= 8192); between there
+  // and N = 16384 round 2's small-launch rule (2 workgroups per CU, combine kernel) measured 21-30 % behind the large-launch one
+  // (profiles/r03_sweep_boundary_n*.txt: N = 12288 59.5 us per step against 41.6); fp64, which has no 16-wave regime: below
+  // N = 4096 only (N = 4096 24.6 us with the small-launch rule, 19.9 with the large one; 8192: 63.6 / 49.6; 12288: 130.8 / 97.6)
+  const bool small = g.fp64 ? n_local < 4096 : (n_local + 63) / 64 <= cus / 2;
   int sub = g.opt.jsub;
   if (sub == 0) {
     // workgroups per launch-slice: the step's launches together have 128 (2) per CU whatever the rank count, so that
@@ -206,7 +210,9 @@ void resolve_config() {
     const int target_blocks = std::max(1, (small ? 2 : 128) * cus / g.nslices);
     sub = (target_blocks + blocks - 1) / blocks;
     int slice_len = g.n / g.nslices;
-    int max_sub = std::max(1, slice_len / 128);    // keep >= 128 sources per segment (a wave walks its segment serially)
+    // keep >= 128 sources per piece of a slice (a wave walks its piece serially); fp64, whose loop takes 4 sources per
+    // iteration, >= 64 (N = 4096 fp64: 16 segments x 4 pieces of 64 sources 19.9 us per step, 8 x 4 of 128: 23.1)
+    int max_sub = std::max(1, slice_len / (g.fp64 ? 64 : 128));
     sub = std::max(sub, (slice_len + 131071) / 131072);   // and <= 131072 sources (a workgroup's lifetime: the launch's tail)
     // ... unless the partial sums (nseg words per body) would then exceed 16 GiB per rank (288 GB are there to be used): at that
     // size (N >= 32M fp32, 16M fp64) a workgroup's lifetime is a negligible part of a step of minutes anyway; never below 8 segments
@@ -447,9 +453,8 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   a.slice_start = slice_start;
   const int R = g.R;
   dim3 grid(blocks_for(row_count, R, g.wsplit), nsl * g.sub, 1);
-  // few workgroups per CU = few waves per SIMD and short segments: the scalar loads are no longer hidden by other waves
+  // few waves per SIMD and short pieces: the scalar loads are no longer hidden by other waves
   const int cus = g.cu_count > 0 ? g.cu_count : 256;
-  // (measured at N = 16384, 16 workgroups per CU: +4 % with the long buffers; N = 65536, 64 per CU: -2 %)
   // XCD-aware placement of segments (block_segment): needs a multiple of 8 segment rows in the launch, or 1/2/4 of them and a
   // row-block count the 8 / rows XCDs of a segment can deal evenly.  Automatic: for launches whose source set is larger than one
   // XCD's L2 share (N = 1M on one GPU: sources fetched once per XCD, 477 MB of memory-side traffic per step
@@ -458,7 +463,9 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   const bool xcd_ok = grid.y % 8 == 0 || ((grid.y == 1 || grid.y == 2 || grid.y == 4) && grid.x % (8 / grid.y) == 0);
   const bool xcd_auto = (long long)blocks_for(row_count, 1, 1) >= 4096;
   a.xcd_map = ((g.opt.xcd_map > 0 || (g.opt.xcd_map < 0 && xcd_auto)) && xcd_ok) ? 1 : 0;
-  a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y * (wg_threads(a.wsplit) / 64) < 128LL * cus ? 1 : 0) : g.opt.long_buffers;
+  // (r03, wall clock per step: 16384 waves in the launch (N = 16384) 68.0 us with the long buffers against 69.5, 20480 waves
+  //  101.7 / 102.9, 24576 waves 144.2 / 142.2, 32768 waves 249.6 / 246.6: the switch sits at 88 waves per CU)
+  a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y * (wg_threads(a.wsplit) / 64) < 88LL * cus ? 1 : 0) : g.opt.long_buffers;
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
     if (g.opt.isa_phase == 2) return launch_isa_f64<2>(L, grid, a);
     return g.opt.isa_phase == 0 ? launch_isa_f64<0>(L, grid, a) : launch_isa_f64<1>(L, grid, a);
