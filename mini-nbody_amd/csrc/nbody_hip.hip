@@ -199,9 +199,10 @@ void resolve_config() {
   const int blocks = blocks_for(n_local, R, 1);   // in workgroups of 256*R rows: `sub` below counts pieces of a slice as round 2 did
   // "small" = the latency regime: fp32: where the 16-wave workgroups are the automatic choice (n_local <= 8192); between there
   // and N = 16384 round 2's small-launch rule (2 workgroups per CU, combine kernel) measured 21-30 % behind the large-launch one
-  // (profiles/r03_sweep_boundary_n*.txt: N = 12288 59.5 us per step against 41.6); fp64, which has no 16-wave regime: below
-  // N = 4096 only (N = 4096 24.6 us with the small-launch rule, 19.9 with the large one; 8192: 63.6 / 49.6; 12288: 130.8 / 97.6)
-  const bool small = g.fp64 ? n_local < 4096 : (n_local + 63) / 64 <= cus / 2;
+  // (profiles/r03_sweep_boundary_n*.txt: N = 12288 59.5 us per step against 41.6); fp64, which has no 16-wave regime: never
+  // (small-launch rule against large: N = 512 13.7 / 12.8 us per step, 1024: 14.4 / 13.0, 2048: 15.5 / 13.6, 4096: 24.6 / 19.9,
+  //  8192: 63.6 / 49.6, 12288: 130.8 / 97.6)
+  const bool small = g.fp64 ? false : (n_local + 63) / 64 <= cus / 2;
   int sub = g.opt.jsub;
   if (sub == 0) {
     // workgroups per launch-slice: the step's launches together have 128 (2) per CU whatever the rank count, so that
