@@ -169,6 +169,25 @@ def tail(path, n=600):
         return ""
 
 
+def _worker_preexec():
+    """in the child, before exec: its own session (so that the supervisor can end the whole group, and only that group) and
+    a parent-death signal (a supervisor that is killed outright must not leave workers holding GPUs)"""
+    os.setsid()
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)      # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
+class Terminated(BaseException):
+    """SIGTERM / SIGINT reached the supervisor: unwind through the clean-up that ends the workers"""
+
+
+def _raise_terminated(signum, frame):
+    raise Terminated("signal %d" % signum)
+
+
 def start_worker(cmd, rank, local, world, port, transport, logdir, attempt, extra_env=None):
     env = dict(os.environ)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(local), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
@@ -180,10 +199,10 @@ def start_worker(cmd, rank, local, world, port, transport, logdir, attempt, extr
     env.pop("OMP_NUM_THREADS", None)      # torch.distributed.run pins it to 1; the CPU-baseline leg wants the host's cores
     if extra_env:
         env.update(extra_env)
-    out = open(os.path.join(logdir, "a%d_rank%d.out" % (attempt, rank)), "w")
-    err = open(os.path.join(logdir, "a%d_rank%d.err" % (attempt, rank)), "w")
     full = list(cmd) + (["--transport", transport] if transport else [])
-    return subprocess.Popen(full, env=env, stdout=out, stderr=err, start_new_session=True), out.name, err.name
+    with open(os.path.join(logdir, "a%d_rank%d.out" % (attempt, rank)), "w") as out, \
+         open(os.path.join(logdir, "a%d_rank%d.err" % (attempt, rank)), "w") as err:
+        return subprocess.Popen(full, env=env, stdout=out, stderr=err, preexec_fn=_worker_preexec), out.name, err.name
 
 
 def wait_workers(procs, deadline_s, peers_failed=lambda: None, poll=0.1):
@@ -242,7 +261,14 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
                             return 1, None
                         time.sleep(0.05)
                     port = int(open(pfile).read())
-            procs = [start_worker(worker_cmd, r, r, world, port, tr, logdir, attempt, extra_env) for r in my_ranks]
+            procs = []
+            try:
+                for r in my_ranks:
+                    procs.append(start_worker(worker_cmd, r, r, world, port, tr, logdir, attempt, extra_env))
+            except BaseException:       # a worker could not be started: do not leave the ones that were behind
+                for p, _, _ in procs:
+                    kill_group(p)
+                raise
 
             def peers_failed():
                 if rdzv_dir is None:
@@ -258,7 +284,12 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
                         return "a peer supervisor reported: " + txt
                 return None
 
-            reason = wait_workers(procs, deadline_s, peers_failed)
+            try:
+                reason = wait_workers(procs, deadline_s, peers_failed)
+            except BaseException:       # interrupted (Ctrl-C, the launcher's SIGTERM): the workers go with the supervisor
+                for p, _, _ in procs:
+                    kill_group(p)
+                raise
             if rdzv_dir is not None:
                 for r in my_ranks:      # this supervisor's verdict, then everybody's
                     vf = os.path.join(rdzv_dir, "verdict.%d.%d" % (attempt, r))
@@ -297,6 +328,11 @@ def supervisor_main(args, argv):
     if os.environ.get(WORKER_ENV) or args.gpus <= 1:
         return None
     world_env = os.environ.get("WORLD_SIZE")
+    for sig in (signal.SIGTERM, signal.SIGINT):      # a launcher's time limit must end the workers too, not orphan them
+        try:
+            signal.signal(sig, _raise_terminated)
+        except ValueError:                            # not the main thread (tests call supervise() directly)
+            pass
     cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--no-supervise"]
     # drop a --transport given on the command line: the supervisor passes the one of the attempt
     clean = []

@@ -107,3 +107,45 @@ def test_command_line_entry_without_world_size(tmp_path):
     assert r.returncode == 1
     assert "attempt 0 (--transport auto) failed" in r.stderr and "attempt 1 (--transport host) failed" in r.stderr
     assert "needs a GPU" in r.stderr
+
+
+def test_sigterm_to_the_supervisor_ends_the_workers(tmp_path):
+    """a launcher's time limit (SIGTERM to `python bench.py --gpus N`) must not leave workers behind holding GPUs: the
+    supervisor unwinds through its clean-up, and a supervisor killed outright takes its workers with it (parent-death signal)"""
+    import signal
+    import time
+    pidfile = tmp_path / "pids"
+    stub = tmp_path / "sleeper.py"
+    stub.write_text("import os, time\nopen(%r, 'a').write(str(os.getpid()) + '\\n')\ntime.sleep(600)\n" % str(pidfile))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent('''
+        import signal, sys
+        sys.path.insert(0, %r)
+        import bench
+        for s in (signal.SIGTERM, signal.SIGINT):
+            signal.signal(s, bench._raise_terminated)
+        bench.supervise([sys.executable, %r], 2, [0, 1], "auto", deadline_s=300)
+    ''') % (ROOT, str(stub)))
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+            return open("/proc/%d/stat" % pid).read().split()[2] != "Z"
+        except (OSError, IOError):
+            return False
+
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        if pidfile.exists():
+            pidfile.unlink()
+        p = subprocess.Popen([sys.executable, str(driver)])
+        t0 = time.time()
+        while time.time() - t0 < 30 and (not pidfile.exists() or len(pidfile.read_text().split()) < 2):
+            time.sleep(0.1)
+        pids = [int(x) for x in pidfile.read_text().split()]
+        assert len(pids) == 2 and all(alive(q) for q in pids)
+        p.send_signal(sig)
+        p.wait(30)
+        t0 = time.time()
+        while time.time() - t0 < 15 and any(alive(q) for q in pids):
+            time.sleep(0.1)
+        assert not any(alive(q) for q in pids), "workers survived %s of their supervisor" % sig
