@@ -183,7 +183,8 @@ void resolve_config() {
   // per step, profiles/r03_small_n.md: N = 2048 7.5 us against 9.1 with 4 waves, N = 4096 9.7 / 10.2, N = 8192 22.0 / 22.1; from
   // N = 16384 up the two are level in fp32 and 4 waves win by 4 % in fp64, so 4 it is)
   const int cus_ = g.cu_count > 0 ? g.cu_count : 256;
-  const int auto_ws = (!g.fp64 && (n_local + 63) / 64 <= cus_ / 2) ? 16 : 4;
+  // (one-rank contexts only: 8 virtual ranks of 8192 bodies each ran 2335 G pairs/s with 16 waves, 2553 with 4)
+  const int auto_ws = (!g.fp64 && g.nslices == 1 && (n_local + 63) / 64 <= cus_ / 2) ? 16 : 4;
   g.wsplit = !can_split ? 1 : (g.opt.wsplit == 4 || g.opt.wsplit == 16) ? g.opt.wsplit : (g.opt.wsplit < 0 && auto_split) ? auto_ws : 1;
   if (g.wsplit == 16 && g.variant == NBODY_VARIANT_ISA && !g.fp64 && g.opt.isa_phase > 1) g.wsplit = 4;   // diagnostic loop forms: 4 waves
   // Small launches and large ones want different things (profiles/r02_small_n.md, one process, wall clock per step):
@@ -240,6 +241,9 @@ void resolve_config() {
       const int l2_sub = (int)std::min<long long>(std::min(64, std::max(1, mem_sub)), (slice_bytes + (2LL << 20) - 1) / (2LL << 20));
       const int div = g.nslices > 1 ? 2 : g.wsplit;
       sub = std::max((sub + div - 1) / div, l2_sub);
+      // ... and a body never has more than 64 partial sums (8 virtual ranks at N = 262144 with 16 segments per slice, 128 in
+      // all, ran 3.2 % behind one rank)
+      if (g.nslices > 1) sub = std::max(1, std::min(sub, std::max(l2_sub, 64 / g.nslices)));
     }
   }
   g.sub = sub;
@@ -604,17 +608,26 @@ inline int resolved_comm_form() {
   return g.opt.comm;
 }
 
+// ncclGroupStart ... ncclGroupEnd with the end guaranteed on every way out (an error between the two must not leave the
+// library inside an open group)
+struct RcclGroup {
+  bool open = false;
+  int begin() { NCCLC(g_rccl.GroupStart()); open = true; return NBODY_OK; }
+  int end() { open = false; NCCLC(g_rccl.GroupEnd()); return NBODY_OK; }
+  ~RcclGroup() { if (open) (void)g_rccl.GroupEnd(); }
+};
+
 // one RCCL group of a plan: every send and receive of group `grp`, on the comm stream
 int run_plan_group(Local& L, void* dev_full, const std::vector<CommOp>& ops, int grp) {
   const size_t wb = word_bytes();
-  NCCLC(g_rccl.GroupStart());
+  RcclGroup grpguard;
+  NBC(grpguard.begin());
   for (const CommOp& o : ops) {
     if (o.group != grp) continue;
     NCCLC(g_rccl.Send(word_ptr(dev_full, (size_t)o.send_first), (size_t)o.send_count * wb, ncclChar, o.send_peer, L.comm_h, L.comm));
     NCCLC(g_rccl.Recv(word_ptr(dev_full, (size_t)o.recv_first), (size_t)o.recv_count * wb, ncclChar, o.recv_peer, L.comm_h, L.comm));
   }
-  NCCLC(g_rccl.GroupEnd());
-  return NBODY_OK;
+  return grpguard.end();
 }
 
 // One ring step on the comm stream: send `send_bytes` at `send_ptr` to the next rank, receive `recv_bytes` at `recv_ptr`
@@ -623,11 +636,11 @@ int run_plan_group(Local& L, void* dev_full, const std::vector<CommOp>& ops, int
 int ring_step(Local& L, const void* send_ptr, size_t send_bytes, void* recv_ptr, size_t recv_bytes) {
   const int P = g.nranks;
   const int next = (L.rank + 1) % P, prev = (L.rank + P - 1) % P;
-  NCCLC(g_rccl.GroupStart());
+  RcclGroup grpguard;
+  NBC(grpguard.begin());
   NCCLC(g_rccl.Send(send_ptr, send_bytes, ncclChar, next, L.comm_h, L.comm));
   NCCLC(g_rccl.Recv(recv_ptr, recv_bytes, ncclChar, prev, L.comm_h, L.comm));
-  NCCLC(g_rccl.GroupEnd());
-  return NBODY_OK;
+  return grpguard.end();
 }
 
 // RCCL all-gather of one sharded device array in place on the comm stream (multi-process), in the resolved form:
@@ -1281,7 +1294,8 @@ int nbody_comm_selftest_virtual(int vp, int form, long long* bytes_moved) {
   long long moved = 0;
   const int groups = plan[0].empty() ? 0 : plan[0].back().group;
   for (int grp = 1; grp <= groups; ++grp) {
-    NCCLC(g_rccl.GroupStart());
+    RcclGroup grpguard;
+    NBC(grpguard.begin());
     for (int r = 0; r < vp; ++r) {
       for (const CommOp& o : plan[r]) {
         if (o.group != grp) continue;
@@ -1289,13 +1303,13 @@ int nbody_comm_selftest_virtual(int vp, int form, long long* bytes_moved) {
         const CommOp* snd = nullptr;
         for (const CommOp& q : plan[o.recv_peer])
           if (q.group == grp && q.send_peer == r && q.send_first == o.recv_first && q.send_count == o.recv_count) { snd = &q; break; }
-        if (!snd) { (void)g_rccl.GroupEnd(); g_last_line = __LINE__; return NBODY_ERR_STATE; }   // the plans do not pair up
+        if (!snd) { g_last_line = __LINE__; return NBODY_ERR_STATE; }   // the plans do not pair up
         NCCLC(g_rccl.Send(word_ptr(bufs.d[o.recv_peer], (size_t)snd->send_first), (size_t)snd->send_count * wb, ncclChar, 0, L.comm_h, L.comm));
         NCCLC(g_rccl.Recv(word_ptr(bufs.d[r], (size_t)o.recv_first), (size_t)o.recv_count * wb, ncclChar, 0, L.comm_h, L.comm));
         moved += o.recv_count * (long long)wb;
       }
     }
-    NCCLC(g_rccl.GroupEnd());
+    NBC(grpguard.end());
   }
   HIPC(hipStreamSynchronize(L.comm));
   for (int r = 0; r < vp; ++r) {
