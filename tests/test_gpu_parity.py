@@ -419,10 +419,13 @@ def test_one_launch_combine_equals_combine_kernel(nb, engine_factory):
                 assert np.array_equal(bits(x), bits(y)), (n, variant, iblock, jsub, jsl)
     # a long run under load (many resident workgroups per CU, thousands of hand-offs per step, partial buffers and
     # tickets reused every step): any stale or torn read of a partial sum changes the final bits
-    for n, steps, ws, nseg in ((20000, 3000, 4, 16), (20000, 1500, 1, 64), (65536 + 77, 300, 4, 16), (65536 + 77, 150, 1, 64)):
+    for n, steps, ws, nseg in ((20000, 3000, 4, 16), (20000, 1500, 1, 64), (65536 + 77, 300, 4, 16), (65536 + 77, 150, 1, 64),
+                               (6000 + 5, 3000, 16, 4), (16384, 1000, 16, 1)):
         pos, vel = nb.make_bodies(n, seed=7)
         eng = engine_factory(n)
         eng.set_option(nb.OPT_WSPLIT, ws)
+        if ws == 16:
+            eng.set_option(nb.OPT_JSUB, nseg)       # 16-wave workgroups: 4 segments (hand-off) and 1 (no global partial sums at all)
         out = {}
         for fuse in (1, 0):
             eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
