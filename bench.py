@@ -15,8 +15,9 @@ the max-over-ranks and torch.cuda.synchronize() only.  `--fp64 --bodies 4194304`
 Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts and SUPERVISES its own N
 worker processes (one per GPU; the parent never touches a GPU); under torch.distributed.run every rank process supervises
 its own worker and the N supervisors agree through a directory under /tmp.  A worker that fails, or a job that passes
---deadline seconds (an RCCL hang has no other symptom), is killed and the job is started once more with --transport host
-(positions staged through host memory and torch.distributed); the line then says so in config.comm.  Workers run the
+--deadline seconds (an RCCL hang has no other symptom), is killed and the job is started again — with --transport peer (rank 0
+drives all the GPUs from one process with peer copies over xGMI: nothing of RCCL is needed), and if that fails too with --transport
+host (positions staged through host memory and torch.distributed); the line then says so in config.comm.  Workers run the
 library's transport self-test (nbody_comm_selftest: every received word checked) before the warm-up.
 
 Rank 0 prints ONE JSON line, always with:
@@ -241,7 +242,10 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
     logdir = tempfile.mkdtemp(prefix="nbody_bench_logs_")
     lead = 0 in my_ranks
     first_reason = None
-    attempts = [transport] + (["host"] if transport != "host" else [])
+    # what is tried, in order: the requested transport (RCCL: one process per GPU, the intended path); then ONE process driving all
+    # the GPUs with peer copies over xGMI (needs nothing from RCCL, costs the host ~0.4 ms of launches per step at 8 GPUs); then
+    # positions staged through host memory (needs nothing from the GPU fabric at all)
+    attempts = [transport] + [t for t in ("peer", "host") if t != transport and not (transport == "host" and t == "peer")]
     try:
         for attempt, tr in enumerate(attempts):
             # ---- the workers' rendezvous port: chosen by the supervisor of rank 0, published through rdzv_dir
@@ -385,7 +389,10 @@ def main(argv=None):
     ap.add_argument("--fuse", type=int, default=-1, help="1: one launch per step (in-launch combine), 0: two, -1: auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", choices=["auto", "ring", "allgather", "direct"], default="auto")
-    ap.add_argument("--transport", choices=["auto", "rccl", "host"], default="auto")
+    ap.add_argument("--transport", choices=["auto", "rccl", "peer", "host"], default="auto",
+                    help="how positions travel between GPUs: rccl (one process per GPU, RCCL over xGMI; auto = rccl, falling back to host when "
+                         "RCCL cannot be set up), peer (rank 0 drives all the GPUs from one process with peer copies, the other ranks idle), "
+                         "host (staged through host memory and torch.distributed)")
     ap.add_argument("--xcd-map", type=int, default=-1, help="XCD-aware placement of source segments: 1 on, 0 off, -1 the engine's default")
     ap.add_argument("--overlap", type=int, default=1, help="0 gather first, 1 own slice then the rest, 2 one launch per arriving slice")
     ap.add_argument("--wsplit", type=int, default=-1, help="4: 64-row workgroups whose waves split the segment, 1: round 2's layout, -1: the engine's choice")
@@ -416,10 +423,13 @@ def main(argv=None):
     rank, world, local = D.env_rank()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local % torch.cuda.device_count())
-    os.environ.setdefault("NBODY_DEVICE", str(local % torch.cuda.device_count()))
+    peer = world > 1 and args.transport == "peer"    # one process (rank 0) drives all the GPUs; the other ranks keep the barriers only
+    if not (peer and rank != 0):                     # (those never touch a GPU, not even to ask whether one is there)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if not peer:
+        os.environ.setdefault("NBODY_DEVICE", str(local % torch.cuda.device_count()))
     import torch.distributed as dist
     if world > 1:
         D.init_process_group(backend="gloo")   # control plane only; the data path is RCCL inside the library
@@ -429,7 +439,18 @@ def main(argv=None):
             dist.barrier()
 
     n = args.n
-    eng = D.make_engine(n, fp64=args.fp64, tile=args.tile, transport=args.transport)
+    if peer and rank != 0:
+        barrier()                                              # before the timed region
+        barrier()                                              # after it
+        dist.all_reduce(torch.zeros(3, dtype=torch.float64), op=dist.ReduceOp.MAX)
+        barrier()                                              # rank 0's CPU-baseline leg is over
+        dist.destroy_process_group()
+        return
+    if peer:
+        eng = nb.NBody(n, fp64=args.fp64, tile=args.tile, ngpus=world)
+        eng.transport = "peer copies over xGMI, one process driving all %d GPUs" % world
+    else:
+        eng = D.make_engine(n, fp64=args.fp64, tile=args.tile, transport=args.transport)
     eng.set_option(nb.OPT_VARIANT, {"auto": nb.VARIANT_AUTO, "smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS,
                                     "readlane": nb.VARIANT_READLANE, "isa": nb.VARIANT_ISA}[args.variant])
     if args.isa_phase >= 0:
@@ -489,7 +510,7 @@ def main(argv=None):
     cfg = eng.config
     # sanity of the state the timed steps produced: this rank's own slice, without any collective (nothing after the
     # timed region may stall the report)
-    p_own, _ = eng.download_slice()
+    p_own, _ = eng.download() if peer else eng.download_slice()
     finite = bool(np.isfinite(p_own).all())
 
     if rank == 0:
@@ -498,6 +519,8 @@ def main(argv=None):
         value = pairs_per_step * args.steps / elapsed / 1e9
         n_local = cfg["n_local"]
         # force kernel: per launch this rank's share of the pairs; duration from HIP events on the compute stream
+        if peer:
+            launches //= world          # the one process timed the launches of all its devices; the durations are the slowest device's
         launches_per_step = max(1, launches // max(1, kernel_steps))
         pairs_per_launch = float(n_local) * float(n) / launches_per_step
         avg_launch_s = kernel_ms * 1e-3 / max(1, launches)
@@ -549,8 +572,8 @@ def main(argv=None):
                                    % (n, "fp64" if args.fp64 else "fp32", args.seed),
                        "n_bodies": n, "pairs_per_step": pairs_per_step, "parallelism": "bodies sharded over %d GPU(s)" % world,
                        "kernel": cfg, "kernel_source_sha": kernel_source_sha(),
-                       "comm": ("%s / %s / overlap %d / stream priority %d" % (COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?"), transport, args.overlap,
-                                                                        eng.info(nb._lib.INFO_COMM_PRIORITY))) if world > 1 else None,
+                       "comm": ("%s / %s / overlap %d / stream priority %d" % ("hipMemcpyPeerAsync" if peer else COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?"),
+                                                                        transport, args.overlap, eng.info(nb._lib.INFO_COMM_PRIORITY))) if world > 1 else None,
                        "graph_replay": bool(world == 1 and not inline and args.steps >= 4),
                        "finite": finite},
             "roofline": roof,

@@ -22,7 +22,8 @@ STUB = textwrap.dedent('''
     mode = os.environ.get("STUB_MODE", "ok")
     assert os.environ["NBODY_BENCH_WORKER"] == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1"
     assert "TORCHELASTIC_USE_AGENT_STORE" not in os.environ and "OMP_NUM_THREADS" not in os.environ
-    if transport != "host":
+    if transport not in ("host", "peer") or (transport == "peer" and mode.endswith("twice")):
+        mode = mode.replace("twice", "")
         if mode == "fail" and rank == world - 1:
             sys.stderr.write("RCCL error 5 near nbody_hip.hip:123\\n")
             sys.exit(3)
@@ -32,7 +33,7 @@ STUB = textwrap.dedent('''
             time.sleep(3600)      # the others wait for rank 0 in a collective
     if rank == 0:
         print("noise before the line")
-        print(json.dumps({"metric": "stub", "n_gpus": world, "config": {"comm": "allgather / %s / overlap 1" % ("host-staged" if transport == "host" else "rccl")},
+        print(json.dumps({"metric": "stub", "n_gpus": world, "config": {"comm": "allgather / %s / overlap 1" % {"host": "host-staged", "peer": "peer copies"}.get(transport, "rccl")},
                           "env": {k: os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}, "argv": sys.argv[1:]}))
 ''')
 
@@ -51,12 +52,17 @@ def test_bare_launch_starts_one_worker_per_gpu(stub):
     assert obj["argv"][-2:] == ["--transport", "auto"] and obj["config"]["comm"].startswith("allgather / rccl")
 
 
-def test_failing_worker_is_retried_on_the_host_transport(stub):
+def test_failing_worker_is_retried_without_rccl(stub):
+    """first fallback: one process driving all GPUs with peer copies; second: the host-staged transport"""
     code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extra_env={"STUB_MODE": "fail"})
     assert code == 0
-    assert "host-staged" in obj["config"]["comm"] and "rccl attempt: worker exited with code 3" in obj["config"]["comm"]
+    assert "peer copies" in obj["config"]["comm"] and "rccl attempt: worker exited with code 3" in obj["config"]["comm"]
     assert "RCCL error 5" in obj["config"]["comm"]
-    assert obj["argv"][-2:] == ["--transport", "host"]
+    assert obj["argv"][-2:] == ["--transport", "peer"]
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extra_env={"STUB_MODE": "failtwice"})
+    assert code == 0 and "host-staged" in obj["config"]["comm"] and obj["argv"][-2:] == ["--transport", "host"]
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "host", deadline_s=60, extra_env={"STUB_MODE": "ok"})     # asked for host: nothing else is tried
+    assert code == 0 and obj["argv"][-2:] == ["--transport", "host"]
 
 
 def test_hang_is_killed_at_the_deadline_and_retried(stub):
@@ -92,7 +98,7 @@ def test_one_supervisor_per_rank_agree_through_the_shared_directory(stub, tmp_pa
     if mode == "ok":
         assert "rccl attempt" not in res[0][1]["config"]["comm"]
     else:
-        assert "host-staged" in res[0][1]["config"]["comm"] and "rccl attempt:" in res[0][1]["config"]["comm"]
+        assert "peer copies" in res[0][1]["config"]["comm"] and "rccl attempt:" in res[0][1]["config"]["comm"]
 
 
 def test_command_line_entry_without_world_size(tmp_path):
@@ -105,7 +111,8 @@ def test_command_line_entry_without_world_size(tmp_path):
     if has_gpu():
         pytest.skip("a GPU is present: covered by the -m gpu test")
     assert r.returncode == 1
-    assert "attempt 0 (--transport auto) failed" in r.stderr and "attempt 1 (--transport host) failed" in r.stderr
+    assert "attempt 0 (--transport auto) failed" in r.stderr and "attempt 1 (--transport peer) failed" in r.stderr
+    assert "attempt 2 (--transport host) failed" in r.stderr
     assert "needs a GPU" in r.stderr
 
 

@@ -105,3 +105,19 @@ def test_bench_launches_and_supervises_its_own_workers(tmp_path):
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
     assert "host-staged" in out["config"]["comm"] or "rccl" in out["config"]["comm"]
     assert out["comm_exposed_ms_per_step"] >= 0 and out["config"]["kernel"]["nranks"] == 2
+
+
+def test_bench_peer_copy_transport(tmp_path):
+    """`--transport peer`, the first fallback when RCCL cannot be used: rank 0 drives all the GPUs from one process with
+    peer copies (here: two virtual ranks on the one GPU), the other rank only keeps the barriers."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NBODY_OVERSUBSCRIBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "262144", "--steps", "3", "--warmup", "1",
+                        "--transport", "peer", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["finite"]
+    assert "hipMemcpyPeerAsync" in out["config"]["comm"] and "one process driving all 2 GPUs" in out["config"]["comm"]
+    assert out["config"]["kernel"]["nranks"] == 2 and out["config"]["kernel"]["launches_per_step"] == 2
+    assert out["roofline"]["kernel_launches"] == 2 * 3 and 0 < out["roofline"]["frac"] < 1
