@@ -245,7 +245,10 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
     # what is tried, in order: the requested transport (RCCL: one process per GPU, the intended path); then ONE process driving all
     # the GPUs with peer copies over xGMI (needs nothing from RCCL, costs the host ~0.4 ms of launches per step at 8 GPUs); then
     # positions staged through host memory (needs nothing from the GPU fabric at all)
-    attempts = [transport] + [t for t in ("peer", "host") if t != transport and not (transport == "host" and t == "peer")]
+    # ("auto" would fall back to the host transport inside the worker when RCCL cannot be set up; under supervision the better
+    #  fallback is the next attempt's, so the first attempt insists on RCCL)
+    first = "rccl" if transport == "auto" else transport
+    attempts = [first] + [t for t in ("peer", "host") if t != first and not (first == "host" and t == "peer")]
     try:
         for attempt, tr in enumerate(attempts):
             # ---- the workers' rendezvous port: chosen by the supervisor of rank 0, published through rdzv_dir

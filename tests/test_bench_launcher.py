@@ -49,7 +49,7 @@ def test_bare_launch_starts_one_worker_per_gpu(stub):
     code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extra_env={"STUB_MODE": "ok"})
     assert code == 0 and obj["n_gpus"] == 3
     assert obj["env"]["RANK"] == "0" and obj["env"]["WORLD_SIZE"] == "3" and int(obj["env"]["MASTER_PORT"]) > 0
-    assert obj["argv"][-2:] == ["--transport", "auto"] and obj["config"]["comm"].startswith("allgather / rccl")
+    assert obj["argv"][-2:] == ["--transport", "rccl"] and obj["config"]["comm"].startswith("allgather / rccl")
 
 
 def test_failing_worker_is_retried_without_rccl(stub):
@@ -111,7 +111,7 @@ def test_command_line_entry_without_world_size(tmp_path):
     if has_gpu():
         pytest.skip("a GPU is present: covered by the -m gpu test")
     assert r.returncode == 1
-    assert "attempt 0 (--transport auto) failed" in r.stderr and "attempt 1 (--transport peer) failed" in r.stderr
+    assert "attempt 0 (--transport rccl) failed" in r.stderr and "attempt 1 (--transport peer) failed" in r.stderr
     assert "attempt 2 (--transport host) failed" in r.stderr
     assert "needs a GPU" in r.stderr
 

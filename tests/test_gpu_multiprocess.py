@@ -90,8 +90,9 @@ def test_two_processes_one_gpu_host_transport(nb, tmp_path, world, overlap):
 
 def test_bench_launches_and_supervises_its_own_workers(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts two fresh worker processes (it never touches the GPU
-    itself), both share this box's one GPU, RCCL refuses a second rank on the same device and the job runs on the host
-    transport — one JSON line with n_gpus 2, roofline, cpu_baseline, the transport used and the exposed communication."""
+    itself), both share this box's one GPU, RCCL refuses a second rank on the same device, the supervisor ends that attempt
+    and the job runs again on the peer-copy transport (one process, two virtual ranks) — one JSON line with n_gpus 2,
+    roofline, cpu_baseline, the transport used, why RCCL was not, and the exposed communication."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["NBODY_OVERSUBSCRIBE"] = "1"
@@ -103,7 +104,7 @@ def test_bench_launches_and_supervises_its_own_workers(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["finite"]
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
-    assert "host-staged" in out["config"]["comm"] or "rccl" in out["config"]["comm"]
+    assert "peer copies" in out["config"]["comm"] and "rccl attempt:" in out["config"]["comm"] and "RCCL error" in out["config"]["comm"]
     assert out["comm_exposed_ms_per_step"] >= 0 and out["config"]["kernel"]["nranks"] == 2
 
 
