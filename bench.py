@@ -163,7 +163,7 @@ def kill_group(proc, grace=5.0):
             time.sleep(0.05)
 
 
-def tail(path, n=600):
+def tail(path, n=320):
     try:
         return open(path, errors="replace").read()[-n:].strip().replace("\n", " | ")
     except OSError:
@@ -324,7 +324,7 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
                     return 0, obj
             print("[bench supervisor] attempt %d (--transport %s) failed: %s" % (attempt, tr, reason), file=log, flush=True)
             if first_reason is None:
-                first_reason = reason[:300]
+                first_reason = reason if len(reason) <= 420 else reason[:60] + " ... " + reason[-340:]
         return 1, None
     finally:
         shutil.rmtree(logdir, ignore_errors=True)
