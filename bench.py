@@ -139,6 +139,7 @@ def matching_pmc(run_cfg):
 # ---------------------------------------------------------------------------------------------------------------------
 # Supervision of the worker processes.  Nothing in this section imports torch or touches a GPU.
 WORKER_ENV = "NBODY_BENCH_WORKER"
+READY_ENV = "NBODY_BENCH_READY_FILE"
 
 
 def free_port():
@@ -200,16 +201,25 @@ def start_worker(cmd, rank, local, world, port, transport, logdir, attempt, extr
     env.pop("OMP_NUM_THREADS", None)      # torch.distributed.run pins it to 1; the CPU-baseline leg wants the host's cores
     if extra_env:
         env.update(extra_env)
+    env[READY_ENV] = os.path.join(logdir, "a%d_rank%d.ready" % (attempt, rank))    # the worker touches it once its engine and transport are up
     full = list(cmd) + (["--transport", transport] if transport else [])
     with open(os.path.join(logdir, "a%d_rank%d.out" % (attempt, rank)), "w") as out, \
          open(os.path.join(logdir, "a%d_rank%d.err" % (attempt, rank)), "w") as err:
         return subprocess.Popen(full, env=env, stdout=out, stderr=err, preexec_fn=_worker_preexec), out.name, err.name
 
 
-def wait_workers(procs, deadline_s, peers_failed=lambda: None, poll=0.1):
-    """-> None when every worker exited 0, else a reason string.  peers_failed() lets sibling supervisors report."""
+def wait_workers(procs, deadline_s, peers_failed=lambda: None, poll=0.1, startup_s=None, ready_files=()):
+    """-> None when every worker exited 0, else a reason string.  peers_failed() lets sibling supervisors report.
+    startup_s: every worker must have touched its ready file (engine created, transport self-test passed) within that many
+    seconds — where a transport hangs it hangs in its first collective, and that is noticed sooner than the whole deadline."""
     t0 = time.time()
+    started = not ready_files or startup_s is None
     while True:
+        if not started:
+            if all(os.path.exists(f) for f in ready_files):
+                started = True
+            elif time.time() - t0 > startup_s:
+                return "timed out after %.0f s before the transport was up" % startup_s
         codes = [p.poll() for p, _, _ in procs]
         bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
         if bad:
@@ -233,7 +243,7 @@ def json_line(path):
         return None
 
 
-def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None, log=sys.stderr, extra_env=None):
+def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None, log=sys.stderr, extra_env=None, startup_s=None):
     """Run the job as `world` worker processes, of which this supervisor owns `my_ranks` (all of them when it was started
     bare; one when torch.distributed.run started one supervisor per rank — then rdzv_dir, shared by the supervisors, carries
     the worker port and every supervisor's verdict on an attempt).  Attempt 0 uses `transport`; if a worker fails or the
@@ -292,7 +302,8 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
                 return None
 
             try:
-                reason = wait_workers(procs, deadline_s, peers_failed)
+                ready = [os.path.join(logdir, "a%d_rank%d.ready" % (attempt, r)) for r in my_ranks]
+                reason = wait_workers(procs, deadline_s, peers_failed, startup_s=startup_s, ready_files=ready)
             except BaseException:       # interrupted (Ctrl-C, the launcher's SIGTERM): the workers go with the supervisor
                 for p, _, _ in procs:
                     kill_group(p)
@@ -355,7 +366,7 @@ def supervisor_main(args, argv):
             continue
         clean.append(a)
     if world_env is None:
-        code, obj = supervise(clean, args.gpus, list(range(args.gpus)), args.transport, args.deadline)
+        code, obj = supervise(clean, args.gpus, list(range(args.gpus)), args.transport, args.deadline, startup_s=args.startup_deadline)
     else:
         world = int(world_env)
         if world != args.gpus:
@@ -364,7 +375,7 @@ def supervisor_main(args, argv):
         # every supervisor of this job has the same parent (the torch.distributed.run agent) and the same MASTER_PORT
         rdzv = os.path.join(tempfile.gettempdir(), "nbody_bench_rdzv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
         os.makedirs(rdzv, exist_ok=True)
-        code, obj = supervise(clean, world, [rank], args.transport, args.deadline, rdzv_dir=rdzv)
+        code, obj = supervise(clean, world, [rank], args.transport, args.deadline, rdzv_dir=rdzv, startup_s=args.startup_deadline)
         if rank == 0:
             time.sleep(0.5)
             shutil.rmtree(rdzv, ignore_errors=True)
@@ -404,6 +415,8 @@ def main(argv=None):
                          "nbody_step() users get (HIP-graph replay, no events) and the kernel duration from a second pass (separate); "
                          "auto: separate when a step is short (one rank's share < 1e10 pairs), where events would change the path")
     ap.add_argument("--deadline", type=float, default=600.0, help="N > 1: seconds a supervised attempt may take before it is killed and retried on the host transport")
+    ap.add_argument("--startup-deadline", type=float, default=300.0,
+                    help="N > 1: seconds within which every worker must have its engine and transport up (first import of torch on a fresh box: 1-2 min)")
     args = ap.parse_args(argv)
     code = supervisor_main(args, argv)
     if code is not None:
@@ -443,6 +456,8 @@ def main(argv=None):
 
     n = args.n
     if peer and rank != 0:
+        if os.environ.get(READY_ENV):
+            open(os.environ[READY_ENV], "w").close()
         barrier()                                              # before the timed region
         barrier()                                              # after it
         dist.all_reduce(torch.zeros(3, dtype=torch.float64), op=dist.ReduceOp.MAX)
@@ -474,6 +489,8 @@ def main(argv=None):
         # every word of a patterned all-gather checked, in the form the steps will use, before anything is timed; a failure
         # ends this worker with a non-zero code and the supervisor starts the job again on the host transport
         eng.comm_selftest()
+    if os.environ.get(READY_ENV):
+        open(os.environ[READY_ENV], "w").close()     # tells the supervisor: engine created, transport up (and self-tested)
     import numpy as np
     pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
     eng.upload(pos, vel)                      # inputs resident in HBM before the timed region

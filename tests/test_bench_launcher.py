@@ -31,6 +31,10 @@ STUB = textwrap.dedent('''
             time.sleep(3600)
         if mode == "hang":
             time.sleep(3600)      # the others wait for rank 0 in a collective
+    if os.environ.get("NBODY_BENCH_READY_FILE") and mode != "noready":
+        open(os.environ["NBODY_BENCH_READY_FILE"], "w").close()
+    if mode == "noready" and transport not in ("host", "peer"):
+        time.sleep(3600)
     if rank == 0:
         print("noise before the line")
         print(json.dumps({"metric": "stub", "n_gpus": world, "config": {"comm": "allgather / %s / overlap 1" % {"host": "host-staged", "peer": "peer copies"}.get(transport, "rccl")},
@@ -68,6 +72,15 @@ def test_failing_worker_is_retried_without_rccl(stub):
 def test_hang_is_killed_at_the_deadline_and_retried(stub):
     code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=1.5, extra_env={"STUB_MODE": "hang"})
     assert code == 0 and "rccl attempt: timed out after" in obj["config"]["comm"]
+
+
+def test_transport_that_never_comes_up_is_noticed_at_the_startup_deadline(stub):
+    """a hang in the first collective: no ready file within --startup-deadline -> killed long before the overall deadline"""
+    import time
+    t0 = time.time()
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=600, startup_s=1.5, extra_env={"STUB_MODE": "noready"})
+    assert code == 0 and time.time() - t0 < 60
+    assert "peer copies" in obj["config"]["comm"] and "before the transport was up" in obj["config"]["comm"]
 
 
 def test_failure_on_the_host_transport_too_is_an_error(stub, tmp_path):
