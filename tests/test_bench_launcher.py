@@ -118,8 +118,9 @@ def test_command_line_entry_without_world_size(tmp_path):
     """python bench.py --gpus 2 (no WORLD_SIZE): the parent only supervises — it must not import torch or need a GPU; with
     the real worker on a box without GPUs both attempts fail and the exit code says so"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--bodies", "4096", "--deadline", "120",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    # (deadlines sized for a fresh container, where the first `import torch` alone can take a minute or two)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--bodies", "4096", "--deadline", "300",
+                        "--startup-deadline", "300", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
     from conftest import has_gpu
     if has_gpu():
         pytest.skip("a GPU is present: covered by the -m gpu test")
