@@ -31,7 +31,7 @@ build/nbody: $(PKG)/host/nbody.c include/nbody.h include/nbody_ic.h $(PKG)/libnb
 oracle:
 	$(MAKE) -C oracle
 
-microbench: build/microbench build/microbench_streams build/microbench_roles
+microbench: build/microbench build/microbench_streams build/microbench_roles build/microbench_mfma
 build/microbench: $(CSRC)/microbench.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
@@ -44,6 +44,13 @@ $(CSRC)/microbench_streams.inc: tools/gen_streams.py tools/gen_force_loop.py
 build/microbench_streams: $(CSRC)/microbench_streams.hip $(CSRC)/microbench_streams.inc
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
+# round 4's probe: can the matrix pipe carry the coordinate differences? (no: profiles/r04_mfma_differences.md); its loop is generated
+$(CSRC)/force_loop_mfma_gfx950.inc: tools/gen_mfma_loop.py
+	python3 tools/gen_mfma_loop.py
+build/microbench_mfma: $(CSRC)/microbench_mfma.hip $(CSRC)/force_loop_mfma_gfx950.inc
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -o $@ $<
 
 # generated sources: the hand-scheduled loop (committed) and the microbenchmark streams (not tracked)
 gen:

@@ -14,11 +14,24 @@ the max-over-ranks and torch.cuda.synchronize() only.  `--fp64 --bodies 4194304`
 
 Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts and SUPERVISES its own N
 worker processes (one per GPU; the parent never touches a GPU); under torch.distributed.run every rank process supervises
-its own worker and the N supervisors agree through a directory under /tmp.  A worker that fails, or a job that passes
---deadline seconds (an RCCL hang has no other symptom), is killed and the job is started again — with --transport peer (rank 0
-drives all the GPUs from one process with peer copies over xGMI: nothing of RCCL is needed), and if that fails too with --transport
-host (positions staged through host memory and torch.distributed); the line then says so in config.comm.  Workers run the
-library's transport self-test (nbody_comm_selftest: every received word checked) before the warm-up.
+its own worker and the N supervisors agree through a directory under /tmp.  A worker that fails, a transport that is not up
+--ready-deadline seconds after `import torch` returned, or an attempt that passes its deadline (an RCCL hang has no other
+symptom) is killed and the job is started again — with --transport peer (rank 0 drives all the GPUs from one process with
+peer copies over xGMI: nothing of RCCL is needed), and if that fails too with --transport host (positions staged through host
+memory and torch.distributed).  The whole command has ONE time budget (--budget, 540 s): an attempt's deadline is what is
+left of it minus a reserve for the attempts still to come, so that every fallback can finish inside the launcher's own limit.
+The line says what ran in machine-readable fields — transport_used, fallback_from, fallback_reason, attempts[{transport,
+seconds, result}] — and --no-fallback turns a failure of the requested transport into exit code 3 instead of a retry (for
+scaling runs where a peer-copy number must not pass as the RCCL point).  Workers run the library's transport self-test
+(nbody_comm_selftest: every received word checked) before the warm-up.
+
+Extras (N > 1 only; the N = 1 path is untouched).  Rank 0 prints the headline line FIRST; then, in the same worker
+processes, (a) three steps each of NBODY_COMM_RING with one launch per arriving slice, NBODY_COMM_DIRECT and
+NBODY_COMM_ALLGATHER -> "comm_forms": {form: {ms_per_step, comm_exposed_ms_per_step, value}} (ring
+against direct over xGMI), and (b) at N = 8 BASELINE configs[4]: an fp64 N = 4,194,304 engine, 1 warm-up + 2 timed steps ->
+"config5": {value, ms_per_step, roofline, hbm_gb_per_s, comm_exposed_ms_per_step}; then a second line = headline + extras,
+which the supervisor prefers.  The extras have their own deadline (--extras-deadline, 90 s after the first line appeared):
+past it the workers are killed and the FIRST line is returned with "extras": "timed out ..." and exit code 0.
 
 Rank 0 prints ONE JSON line, always with:
   roofline      the force kernel priced at 20 flop per pair against the fp32 (157.3 TFLOP/s) or
@@ -139,7 +152,11 @@ def matching_pmc(run_cfg):
 # ---------------------------------------------------------------------------------------------------------------------
 # Supervision of the worker processes.  Nothing in this section imports torch or touches a GPU.
 WORKER_ENV = "NBODY_BENCH_WORKER"
-READY_ENV = "NBODY_BENCH_READY_FILE"
+READY_ENV = "NBODY_BENCH_READY_FILE"          # the worker touches it once its engine and transport are up (and self-tested)
+IMPORTED_ENV = "NBODY_BENCH_IMPORTED_FILE"    # ... and this one as soon as `import torch` has returned
+WARM_IMPORT_S = 15.0      # what a LATER attempt's `import torch` costs: the first one paged the image in (1-2 min), the rest come from the page cache
+RUN_RESERVE_S = 90.0      # what a fallback attempt needs after its import: transport + self-test, warm-up + timed steps, the CPU leg
+EXIT_NO_FALLBACK = 3      # --no-fallback and the requested transport failed
 
 
 def free_port():
@@ -201,57 +218,108 @@ def start_worker(cmd, rank, local, world, port, transport, logdir, attempt, extr
     env.pop("OMP_NUM_THREADS", None)      # torch.distributed.run pins it to 1; the CPU-baseline leg wants the host's cores
     if extra_env:
         env.update(extra_env)
-    env[READY_ENV] = os.path.join(logdir, "a%d_rank%d.ready" % (attempt, rank))    # the worker touches it once its engine and transport are up
+    env[READY_ENV] = os.path.join(logdir, "a%d_rank%d.ready" % (attempt, rank))
+    env[IMPORTED_ENV] = os.path.join(logdir, "a%d_rank%d.imported" % (attempt, rank))
     full = list(cmd) + (["--transport", transport] if transport else [])
     with open(os.path.join(logdir, "a%d_rank%d.out" % (attempt, rank)), "w") as out, \
          open(os.path.join(logdir, "a%d_rank%d.err" % (attempt, rank)), "w") as err:
         return subprocess.Popen(full, env=env, stdout=out, stderr=err, preexec_fn=_worker_preexec), out.name, err.name
 
 
-def wait_workers(procs, deadline_s, peers_failed=lambda: None, poll=0.1, startup_s=None, ready_files=()):
-    """-> None when every worker exited 0, else a reason string.  peers_failed() lets sibling supervisors report.
+def json_lines(path):
+    """every line of `path` that parses as a JSON object, in order (a line still being written is skipped)"""
+    out = []
+    try:
+        for l in open(path).read().splitlines():
+            if l.startswith("{"):
+                try:
+                    out.append(json.loads(l))
+                except ValueError:
+                    pass
+    except OSError:
+        pass
+    return out
+
+
+def json_line(path):
+    lines = json_lines(path)
+    return lines[-1] if lines else None
+
+
+def wait_workers(procs, deadline_s, peers_failed=lambda: None, poll=0.1, startup_s=None, ready_files=(), imported_files=(),
+                 ready_after_import_s=None, line_seen=lambda: False, extras_s=None, info=None):
+    """-> None when the attempt counts as a success, else a reason string.
+    deadline_s: seconds, or a function of the import time measured so far (None until every worker has imported torch).
     startup_s: every worker must have touched its ready file (engine created, transport self-test passed) within that many
-    seconds — where a transport hangs it hangs in its first collective, and that is noticed sooner than the whole deadline."""
+      seconds; ready_after_import_s: ... and within that many after the last worker's `import torch` returned — where a
+      transport hangs it hangs in its first collective, and that is noticed a minute after the import, not at the deadline.
+    line_seen(): rank 0 has printed its headline line.  From then on nothing can fail the attempt: the workers get extras_s
+      more seconds for the extras pass, and a time-out, a crash or a peer's complaint after that moment only sets
+      info["extras"] (the caller then reports the FIRST line).
+    info (dict, filled in): import_s, ready_s, first_line_s, extras."""
+    info = {} if info is None else info
+    info.update({"import_s": None, "ready_s": None, "first_line_s": None, "extras": None})
     t0 = time.time()
-    started = not ready_files or startup_s is None
+    started = not ready_files or (startup_s is None and ready_after_import_s is None)
     while True:
-        if not started:
+        now = time.time() - t0
+        if info["import_s"] is None and imported_files and all(os.path.exists(f) for f in imported_files):
+            info["import_s"] = now
+        if info["first_line_s"] is None and line_seen():
+            info["first_line_s"] = now
+        headline = info["first_line_s"] is not None
+        if not started and not headline:
             if all(os.path.exists(f) for f in ready_files):
                 started = True
-            elif time.time() - t0 > startup_s:
+                info["ready_s"] = now
+            elif ready_after_import_s is not None and info["import_s"] is not None and now - info["import_s"] > ready_after_import_s:
+                return "transport not up %.0f s after `import torch` returned (%.0f s)" % (ready_after_import_s, info["import_s"])
+            elif startup_s is not None and now > startup_s:
                 return "timed out after %.0f s before the transport was up" % startup_s
         codes = [p.poll() for p, _, _ in procs]
         bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
         if bad:
             i, c = bad[0]
-            return "worker exited with code %d: %s" % (c, tail(procs[i][2]) or tail(procs[i][1]))
+            why = "worker exited with code %d: %s" % (c, tail(procs[i][2]) or tail(procs[i][1]))
+            if headline or line_seen():
+                info["extras"] = "failed: " + why
+                return None
+            return why
         if all(c == 0 for c in codes):
             return None
         why = peers_failed()
         if why:
+            if headline:
+                info["extras"] = "failed: " + why
+                return None
             return why
-        if time.time() - t0 > deadline_s:
-            return "timed out after %.0f s" % deadline_s
+        limit = deadline_s(info["import_s"]) if callable(deadline_s) else deadline_s
+        if headline and extras_s is not None and now - info["first_line_s"] > extras_s:
+            info["extras"] = "timed out %.0f s after the headline line" % extras_s
+            return None
+        if now > limit:
+            if headline:
+                info["extras"] = "timed out (attempt deadline %.0f s)" % limit
+                return None
+            return "timed out after %.0f s" % limit
         time.sleep(poll)
 
 
-def json_line(path):
-    try:
-        lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
-        return json.loads(lines[-1]) if lines else None
-    except (OSError, ValueError):
-        return None
-
-
-def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None, log=sys.stderr, extra_env=None, startup_s=None):
+def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None, log=sys.stderr, extra_env=None, startup_s=None,
+              budget_s=None, ready_after_import_s=None, extras_s=None, no_fallback=False, t_start=None,
+              warm_import_s=WARM_IMPORT_S, reserve_s=RUN_RESERVE_S, min_attempt_s=10.0, min_start_s=20.0):
     """Run the job as `world` worker processes, of which this supervisor owns `my_ranks` (all of them when it was started
     bare; one when torch.distributed.run started one supervisor per rank — then rdzv_dir, shared by the supervisors, carries
-    the worker port and every supervisor's verdict on an attempt).  Attempt 0 uses `transport`; if a worker fails or the
-    deadline passes, everything is killed and attempt 1 runs with --transport host.  Returns (exit code, JSON object of
-    rank 0's line or None)."""
+    the worker port, every supervisor's verdict on an attempt and the "headline printed" marker).  Attempt 0 uses
+    `transport`; if a worker fails or a deadline passes, everything is killed and the next attempt runs with --transport
+    peer, then host — unless no_fallback.  budget_s bounds the whole call: attempt k may take
+    min(deadline_s, budget left - (attempts still to come) x (import + reserve_s)), where import = the time this attempt's
+    `import torch` took, capped at warm_import_s: the first import of a fresh box pages the image in (1-2 min), a later
+    attempt's comes from the page cache.
+    Returns (exit code, JSON object of rank 0's line or None)."""
     logdir = tempfile.mkdtemp(prefix="nbody_bench_logs_")
     lead = 0 in my_ranks
-    first_reason = None
+    t_start = time.time() if t_start is None else t_start
     # what is tried, in order: the requested transport (RCCL: one process per GPU, the intended path); then ONE process driving all
     # the GPUs with peer copies over xGMI (needs nothing from RCCL, costs the host ~0.4 ms of launches per step at 8 GPUs); then
     # positions staged through host memory (needs nothing from the GPU fabric at all)
@@ -259,8 +327,26 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
     #  fallback is the next attempt's, so the first attempt insists on RCCL)
     first = "rccl" if transport == "auto" else transport
     attempts = [first] + [t for t in ("peer", "host") if t != first and not (first == "host" and t == "peer")]
+    if no_fallback:
+        attempts = attempts[:1]
+    records = []
+    first_reason = None
     try:
         for attempt, tr in enumerate(attempts):
+            t_a = time.time()
+            to_come = len(attempts) - attempt - 1
+            if budget_s is not None and attempt > 0 and budget_s - (t_a - t_start) < min_start_s:   # no fallback is started on a spent budget
+                records.append({"transport": tr, "seconds": 0.0, "result": "not started: %.0f s of the budget left" % (budget_s - (t_a - t_start))})
+                print("[bench supervisor] attempt %d (--transport %s) not started: budget spent" % (attempt, tr), file=log, flush=True)
+                break
+
+            def attempt_deadline(import_s, t_a=t_a, to_come=to_come):
+                if budget_s is None:
+                    return deadline_s
+                left = budget_s - (t_a - t_start)
+                warm = warm_import_s if import_s is None else min(import_s, warm_import_s)
+                return max(min_attempt_s, min(deadline_s, left - to_come * (warm + reserve_s)))
+
             # ---- the workers' rendezvous port: chosen by the supervisor of rank 0, published through rdzv_dir
             if rdzv_dir is None:
                 port = free_port()
@@ -274,7 +360,7 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
                 else:
                     t0 = time.time()
                     while not os.path.exists(pfile):
-                        if time.time() - t0 > deadline_s:
+                        if time.time() - t0 > attempt_deadline(None):
                             return 1, None
                         time.sleep(0.05)
                     port = int(open(pfile).read())
@@ -301,9 +387,24 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
                         return "a peer supervisor reported: " + txt
                 return None
 
+            marker = os.path.join(rdzv_dir, "line.%d" % attempt) if rdzv_dir is not None else None
+
+            def line_seen():
+                """rank 0's headline line is out (the lead sees the worker's stdout; the others a marker the lead leaves)"""
+                if lead:
+                    if json_line(procs[0][1]) is None:
+                        return False
+                    if marker and not os.path.exists(marker):
+                        open(marker, "w").close()
+                    return True
+                return bool(marker) and os.path.exists(marker)
+
+            info = {}
             try:
                 ready = [os.path.join(logdir, "a%d_rank%d.ready" % (attempt, r)) for r in my_ranks]
-                reason = wait_workers(procs, deadline_s, peers_failed, startup_s=startup_s, ready_files=ready)
+                imported = [os.path.join(logdir, "a%d_rank%d.imported" % (attempt, r)) for r in my_ranks]
+                reason = wait_workers(procs, attempt_deadline, peers_failed, startup_s=startup_s, ready_files=ready, imported_files=imported,
+                                      ready_after_import_s=ready_after_import_s, line_seen=line_seen, extras_s=extras_s, info=info)
             except BaseException:       # interrupted (Ctrl-C, the launcher's SIGTERM): the workers go with the supervisor
                 for p, _, _ in procs:
                     kill_group(p)
@@ -315,28 +416,46 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
                         f.write("ok" if reason is None else reason)
                     os.replace(vf + ".tmp", vf)
                 t0 = time.time()
-                while reason is None:
+                while reason is None and info.get("extras") is None:
                     files = glob.glob(os.path.join(rdzv_dir, "verdict.%d.*" % attempt))
                     reason = peers_failed()
+                    if reason and line_seen():          # the headline is out: a peer's late complaint concerns the extras only
+                        info["extras"], reason = "failed: " + reason, None
+                        break
                     if len([f for f in files if not f.endswith(".tmp")]) >= world or reason:
                         break
-                    if time.time() - t0 > deadline_s:
-                        reason = "peer supervisors did not report within %.0f s" % deadline_s
+                    if time.time() - t0 > attempt_deadline(info.get("import_s")):
+                        reason = "peer supervisors did not report within %.0f s" % attempt_deadline(info.get("import_s"))
                     time.sleep(0.05)
             for p, _, _ in procs:
                 kill_group(p)
+            rec = {"transport": tr, "seconds": round(time.time() - t_a, 1), "result": "ok" if reason is None else reason[:400],
+                   "import_s": None if info.get("import_s") is None else round(info["import_s"], 1)}
+            if info.get("extras"):
+                rec["extras"] = info["extras"][:400]
+            records.append(rec)
             if reason is None:
-                obj = json_line(procs[0][1]) if lead else None
+                lines = json_lines(procs[0][1]) if lead else []
+                # an extras pass that ended badly leaves the headline: the FIRST line; otherwise the last (headline + extras)
+                obj = (lines[0] if info.get("extras") else lines[-1]) if lines else None
                 if lead and obj is None:
                     reason = "rank 0 printed no JSON line: " + tail(procs[0][2])
+                    records[-1]["result"] = reason[:400]
                 else:
-                    if obj is not None and first_reason is not None:
-                        obj.setdefault("config", {})["comm"] = "%s (rccl attempt: %s)" % (obj.get("config", {}).get("comm"), first_reason)
+                    if obj is not None:
+                        if info.get("extras"):
+                            obj["extras"] = info["extras"]
+                        obj["transport_used"] = tr
+                        obj["fallback_from"] = attempts[0] if attempt > 0 else None
+                        obj["fallback_reason"] = first_reason if attempt > 0 else None
+                        obj["attempts"] = records
+                        if first_reason is not None:
+                            obj.setdefault("config", {})["comm"] = "%s (%s attempt: %s)" % (obj.get("config", {}).get("comm"), attempts[0], first_reason)
                     return 0, obj
-            print("[bench supervisor] attempt %d (--transport %s) failed: %s" % (attempt, tr, reason), file=log, flush=True)
+            print("[bench supervisor] attempt %d (--transport %s) failed after %.0f s: %s" % (attempt, tr, time.time() - t_a, reason), file=log, flush=True)
             if first_reason is None:
                 first_reason = reason if len(reason) <= 420 else reason[:60] + " ... " + reason[-340:]
-        return 1, None
+        return (EXIT_NO_FALLBACK if no_fallback else 1), None
     finally:
         shutil.rmtree(logdir, ignore_errors=True)
 
@@ -345,13 +464,14 @@ def supervisor_main(args, argv):
     """-> exit code, or None when this process should run the benchmark itself (one GPU, or it IS a worker)."""
     if os.environ.get(WORKER_ENV) or args.gpus <= 1:
         return None
+    t_start = time.time()
     world_env = os.environ.get("WORLD_SIZE")
     for sig in (signal.SIGTERM, signal.SIGINT):      # a launcher's time limit must end the workers too, not orphan them
         try:
             signal.signal(sig, _raise_terminated)
         except ValueError:                            # not the main thread (tests call supervise() directly)
             pass
-    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--no-supervise"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
     # drop a --transport given on the command line: the supervisor passes the one of the attempt
     clean = []
     skip = False
@@ -365,8 +485,10 @@ def supervisor_main(args, argv):
         if a.startswith("--transport="):
             continue
         clean.append(a)
+    kw = dict(startup_s=args.startup_deadline, budget_s=args.budget if args.budget > 0 else None, ready_after_import_s=args.ready_deadline,
+              extras_s=args.extras_deadline, no_fallback=args.no_fallback, t_start=t_start)
     if world_env is None:
-        code, obj = supervise(clean, args.gpus, list(range(args.gpus)), args.transport, args.deadline, startup_s=args.startup_deadline)
+        code, obj = supervise(clean, args.gpus, list(range(args.gpus)), args.transport, args.deadline, **kw)
     else:
         world = int(world_env)
         if world != args.gpus:
@@ -375,11 +497,12 @@ def supervisor_main(args, argv):
         # every supervisor of this job has the same parent (the torch.distributed.run agent) and the same MASTER_PORT
         rdzv = os.path.join(tempfile.gettempdir(), "nbody_bench_rdzv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
         os.makedirs(rdzv, exist_ok=True)
-        code, obj = supervise(clean, world, [rank], args.transport, args.deadline, rdzv_dir=rdzv, startup_s=args.startup_deadline)
+        code, obj = supervise(clean, world, [rank], args.transport, args.deadline, rdzv_dir=rdzv, **kw)
         if rank == 0:
             time.sleep(0.5)
             shutil.rmtree(rdzv, ignore_errors=True)
     if obj is not None:
+        obj["supervisor_seconds"] = round(time.time() - t_start, 1)
         print(json.dumps(obj), flush=True)
     return code
 
@@ -414,9 +537,22 @@ def main(argv=None):
                     help="HIP events around every force kernel inside the timed region (inline), or the timed region on the path "
                          "nbody_step() users get (HIP-graph replay, no events) and the kernel duration from a second pass (separate); "
                          "auto: separate when a step is short (one rank's share < 1e10 pairs), where events would change the path")
-    ap.add_argument("--deadline", type=float, default=600.0, help="N > 1: seconds a supervised attempt may take before it is killed and retried on the host transport")
+    ap.add_argument("--deadline", type=float, default=600.0, help="N > 1: upper bound in seconds on one supervised attempt (the budget usually binds first)")
+    ap.add_argument("--budget", type=float, default=540.0,
+                    help="N > 1: seconds the WHOLE command may take, fallbacks included: an attempt's deadline is what is left minus a reserve "
+                         "for the attempts still to come (0: no budget, --deadline per attempt)")
     ap.add_argument("--startup-deadline", type=float, default=300.0,
                     help="N > 1: seconds within which every worker must have its engine and transport up (first import of torch on a fresh box: 1-2 min)")
+    ap.add_argument("--ready-deadline", type=float, default=90.0,
+                    help="N > 1: seconds after `import torch` returned within which the transport must be up and self-tested (a hang in the first collective)")
+    ap.add_argument("--extras-deadline", type=float, default=90.0,
+                    help="N > 1: seconds the extras pass may take after the headline line appeared; past it the headline is returned alone")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="N > 1: if the requested transport fails, exit with code 3 instead of retrying on peer copies / the host")
+    ap.add_argument("--extras", choices=["auto", "off", "forms", "all"], default="auto",
+                    help="N > 1: after the headline line, time the three transfer forms (forms) and BASELINE configs[4] in fp64 (all); "
+                         "auto = forms, plus config 5 when N = 8; never at N = 1")
+    ap.add_argument("--config5-bodies", type=int, default=4194304, help="bodies of the extras pass's fp64 run (BASELINE configs[4]: 4,194,304)")
     args = ap.parse_args(argv)
     code = supervisor_main(args, argv)
     if code is not None:
@@ -433,6 +569,8 @@ def main(argv=None):
                 time.sleep(0.5)
             time.sleep(2.0)
     import torch
+    if os.environ.get(IMPORTED_ENV):
+        open(os.environ[IMPORTED_ENV], "w").close()   # tells the supervisor: the image is paged in, what follows is the transport
     nb = importlib.import_module("mini-nbody_amd")
     D = importlib.import_module("mini-nbody_amd.distributed")
 
@@ -455,119 +593,143 @@ def main(argv=None):
             dist.barrier()
 
     n = args.n
-    if peer and rank != 0:
-        if os.environ.get(READY_ENV):
-            open(os.environ[READY_ENV], "w").close()
-        barrier()                                              # before the timed region
-        barrier()                                              # after it
-        dist.all_reduce(torch.zeros(3, dtype=torch.float64), op=dist.ReduceOp.MAX)
-        barrier()                                              # rank 0's CPU-baseline leg is over
-        dist.destroy_process_group()
-        return
-    if peer:
-        eng = nb.NBody(n, fp64=args.fp64, tile=args.tile, ngpus=world)
-        eng.transport = "peer copies over xGMI, one process driving all %d GPUs" % world
-    else:
-        eng = D.make_engine(n, fp64=args.fp64, tile=args.tile, transport=args.transport)
-    eng.set_option(nb.OPT_VARIANT, {"auto": nb.VARIANT_AUTO, "smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS,
-                                    "readlane": nb.VARIANT_READLANE, "isa": nb.VARIANT_ISA}[args.variant])
-    if args.isa_phase >= 0:
-        eng.set_option(nb.OPT_ISA_PHASE, args.isa_phase)
-    eng.set_option(nb.OPT_IBLOCK, args.iblock)
-    eng.set_option(nb.OPT_JSUB, args.jsub)
-    eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED if args.sum == "blocked" else nb.SUM_SEQ)
-    if args.sum_block > 0:
-        eng.set_option(nb.OPT_SUM_BLOCK, args.sum_block)
-    eng.set_option(nb.OPT_FUSE_COMBINE, args.fuse)
-    if args.xcd_map >= 0:
-        eng.set_option(nb.OPT_XCD_MAP, args.xcd_map)
-    eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER, "direct": nb.COMM_DIRECT}[args.comm])
-    eng.set_option(nb.OPT_OVERLAP, args.overlap)
-    eng.set_option(nb.OPT_WSPLIT, args.wsplit)
-    transport = getattr(eng, "transport", "rccl") if world > 1 else None
-    if world > 1 and transport == "rccl":
-        # every word of a patterned all-gather checked, in the form the steps will use, before anything is timed; a failure
-        # ends this worker with a non-zero code and the supervisor starts the job again on the host transport
-        eng.comm_selftest()
-    if os.environ.get(READY_ENV):
-        open(os.environ[READY_ENV], "w").close()     # tells the supervisor: engine created, transport up (and self-tested)
-    import numpy as np
-    pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
-    eng.upload(pos, vel)                      # inputs resident in HBM before the timed region
     dt = 0.01
+    import numpy as np
+    MAXOP = dist.ReduceOp.MAX if world > 1 else None
+    # extras (N > 1 only): the three transfer forms, and BASELINE configs[4] in fp64 at N = 8 (or when asked for)
+    want_forms = world > 1 and args.extras != "off"
+    want_c5 = world > 1 and (args.extras == "all" or (args.extras == "auto" and world == 8))
 
-    share = float(n) * float(n) / world
-    inline = args.events == "inline" or (args.events == "auto" and share >= 1e10)
-    eng.step(dt, args.warmup)
-    eng.sync()
-    eng.set_option(nb.OPT_TIMING, 1 if inline else 0)
-    eng.kernel_time(reset=True)
-    eng.comm_time(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.step(dt, args.steps)                  # EXACTLY K steps
-    eng.sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_steps = args.steps
-    if not inline:
-        # the timed region ran the path nbody_step() users get (one GPU: HIP-graph replay); the kernel's duration comes from
-        # a second pass with events around every launch
-        kernel_steps = min(args.steps, 50)
-        eng.set_option(nb.OPT_TIMING, 1)
-        eng.kernel_time(reset=True)
-        eng.comm_time(reset=True)
-        eng.step(dt, kernel_steps)
-        eng.sync()
-    kernel_ms, launches = eng.kernel_time(reset=True)
-    wait_ms, waits = eng.comm_time(reset=True)
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms, wait_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms, wait_ms = float(t[0]), float(t[1]), float(t[2])
-    cfg = eng.config
-    # sanity of the state the timed steps produced: this rank's own slice, without any collective (nothing after the
-    # timed region may stall the report)
-    p_own, _ = eng.download() if peer else eng.download_slice()
-    finite = bool(np.isfinite(p_own).all())
+    def allmax(vals):
+        """MAX over the ranks of a few numbers (every rank calls it, also a peer-transport rank that holds no engine)"""
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64)
+        dist.all_reduce(t, op=MAXOP)
+        return [float(x) for x in t]
 
-    if rank == 0:
-        dtype = "f64" if args.fp64 else "f32"
-        pairs_per_step = float(n) * float(n)
-        value = pairs_per_step * args.steps / elapsed / 1e9
-        n_local = cfg["n_local"]
-        # force kernel: per launch this rank's share of the pairs; duration from HIP events on the compute stream
+    def run_timed(e, steps, warmup, inline):
+        """W untimed steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both sides; MAX over ranks.
+        e is None on the ranks of a peer-transport job that hold no GPU: they keep the collectives only."""
+        if e is not None:
+            e.step(dt, warmup)
+            e.sync()
+            e.set_option(nb.OPT_TIMING, 1 if inline else 0)
+            e.kernel_time(reset=True)
+            e.comm_time(reset=True)
+        barrier()
+        if e is not None:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if e is not None:
+            e.step(dt, steps)                     # EXACTLY K steps
+            e.sync()
+            torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_steps, kernel_ms, launches, wait_ms, waits = steps, 0.0, 0, 0.0, 0
+        if e is not None:
+            if not inline:
+                # the timed region ran the path nbody_step() users get (one GPU: HIP-graph replay); the kernel's duration comes
+                # from a second pass with events around every launch
+                kernel_steps = min(steps, 50)
+                e.set_option(nb.OPT_TIMING, 1)
+                e.kernel_time(reset=True)
+                e.comm_time(reset=True)
+                e.step(dt, kernel_steps)
+                e.sync()
+            kernel_ms, launches = e.kernel_time(reset=True)
+            wait_ms, waits = e.comm_time(reset=True)
+        elapsed, kernel_ms, wait_ms = allmax([elapsed, kernel_ms, wait_ms])
+        return {"elapsed": elapsed, "kernel_ms": kernel_ms, "launches": launches, "wait_ms": wait_ms, "waits": waits, "kernel_steps": kernel_steps}
+
+    def open_engine(bodies, fp64):
+        """this rank's engine for `bodies` bodies (None: a peer-transport rank other than 0, which never touches a GPU)"""
         if peer:
-            launches //= world          # the one process timed the launches of all its devices; the durations are the slowest device's
-        launches_per_step = max(1, launches // max(1, kernel_steps))
-        pairs_per_launch = float(n_local) * float(n) / launches_per_step
-        avg_launch_s = kernel_ms * 1e-3 / max(1, launches)
+            if rank != 0:
+                return None
+            e = nb.NBody(bodies, fp64=fp64, tile=args.tile, ngpus=world)
+            e.transport = "peer copies over xGMI, one process driving all %d GPUs" % world
+            return e
+        return D.make_engine(bodies, fp64=fp64, tile=args.tile, transport=args.transport)
+
+    def roofline_of(e, cfg, r, bodies, fp64, steps, inline):
+        """the force kernel priced at 20 flop per pair against the vector peak; duration from HIP events on the compute stream"""
+        dtype = "f64" if fp64 else "f32"
+        n_local = cfg["n_local"]
+        launches = r["launches"] // world if peer else r["launches"]   # one process timed the launches of all its devices; durations are the slowest device's
+        launches_per_step = max(1, launches // max(1, r["kernel_steps"]))
+        pairs_per_launch = float(n_local) * float(bodies) / launches_per_step
+        avg_launch_s = r["kernel_ms"] * 1e-3 / max(1, launches)
         kernel_rate = pairs_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0   # pairs/s on one GPU
         achieved_tflops = kernel_rate * FLOP_PER_PAIR / 1e12
         peak = PEAK_VECTOR_TFLOPS[dtype]
-        cu, clk = eng.info(nb._lib.INFO_CU_COUNT), eng.info(nb._lib.INFO_CLOCK_KHZ) * 1e3
+        cu, clk = e.info(nb._lib.INFO_CU_COUNT), e.info(nb._lib.INFO_CLOCK_KHZ) * 1e3
         simds = cu * 4
         issue_bound = simds * 64.0 / ISSUE_CYCLES_PER_WAVE_PAIR[dtype] * clk   # pairs/s at the nominal clock
         wave_pairs_per_launch = pairs_per_launch / 64.0
-        run_cfg = {"n": n, "dtype": dtype, "n_gpus": world, "variant": cfg["variant"], "iblock": cfg["iblock"], "nseg": cfg["nseg"],
-                   "sum_order": cfg["sum_order"], "sum_block": cfg["sum_block"], "launches_per_step": cfg["launches_per_step"],
-                   "wsplit": cfg["wsplit"], "isa_phase": cfg["isa_phase"], "long_buffers": cfg["long_buffers"], "xcd_map": cfg["xcd_map"],
-                   "kernel_source_sha": kernel_source_sha()}
-        roof = {"bound": "valu", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+        return {"bound": "valu", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / peak, 4), "traffic": None, "flop_per_pair": FLOP_PER_PAIR,
                 "kernel_ms_avg": round(avg_launch_s * 1e3, 4), "kernel_launches": launches,
                 "kernel_gpairs_per_s": round(kernel_rate / 1e9, 1),
                 "algorithmic_flops_per_launch": pairs_per_launch * FLOP_PER_PAIR,
-                "algorithmic_hbm_bytes_per_launch": n_local * (32 if args.fp64 else 16) * 4 / launches_per_step,
+                "algorithmic_hbm_bytes_per_launch": n_local * (32 if fp64 else 16) * 4 / launches_per_step,
                 "issue_cycles_per_wave_pair_model": ISSUE_CYCLES_PER_WAVE_PAIR[dtype],
                 "issue_bound_gpairs_per_s": round(issue_bound / 1e9, 1),
                 "frac_of_issue_bound": round(kernel_rate / issue_bound, 4) if issue_bound else None,
                 "cycles_per_wave_pair_at_nominal_clock": round(avg_launch_s * clk * simds / wave_pairs_per_launch, 2) if wave_pairs_per_launch else None,
-                "kernel_events": "inline (inside the timed region)" if inline else "separate pass of %d steps after the timed region (the timed region ran without events%s)" % (kernel_steps, ", HIP-graph replay" if world == 1 else ""),
+                "kernel_events": "inline (inside the timed region)" if inline else "separate pass of %d steps after the timed region (the timed region ran without events%s)" % (r["kernel_steps"], ", HIP-graph replay" if world == 1 else ""),
                 "note": "VALU-issue-bound: per pair 11 full-rate + 1 quarter-rate instruction in fp32 (30 cycles per wave64), "
                         "16 + 1 in fp64 (80); neither HBM nor MFMA bounds it (no contraction; HBM traffic is 64 B per body per step)"}
+
+    eng = open_engine(n, args.fp64)
+    if eng is not None:
+        eng.set_option(nb.OPT_VARIANT, {"auto": nb.VARIANT_AUTO, "smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS,
+                                        "readlane": nb.VARIANT_READLANE, "isa": nb.VARIANT_ISA}[args.variant])
+        if args.isa_phase >= 0:
+            eng.set_option(nb.OPT_ISA_PHASE, args.isa_phase)
+        eng.set_option(nb.OPT_IBLOCK, args.iblock)
+        eng.set_option(nb.OPT_JSUB, args.jsub)
+        eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED if args.sum == "blocked" else nb.SUM_SEQ)
+        if args.sum_block > 0:
+            eng.set_option(nb.OPT_SUM_BLOCK, args.sum_block)
+        eng.set_option(nb.OPT_FUSE_COMBINE, args.fuse)
+        if args.xcd_map >= 0:
+            eng.set_option(nb.OPT_XCD_MAP, args.xcd_map)
+        eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER, "direct": nb.COMM_DIRECT}[args.comm])
+        eng.set_option(nb.OPT_OVERLAP, args.overlap)
+        eng.set_option(nb.OPT_WSPLIT, args.wsplit)
+    transport = (getattr(eng, "transport", "rccl") if eng is not None else "peer") if world > 1 else None
+    if world > 1 and transport == "rccl":
+        # every word of a patterned all-gather checked, in the form the steps will use, before anything is timed; a failure
+        # ends this worker with a non-zero code and the supervisor starts the job again on the next transport
+        eng.comm_selftest()
+    if os.environ.get(READY_ENV):
+        open(os.environ[READY_ENV], "w").close()     # tells the supervisor: engine created, transport up (and self-tested)
+    if eng is not None:
+        pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
+        eng.upload(pos, vel)                      # inputs resident in HBM before the timed region
+
+    share = float(n) * float(n) / world
+    inline = args.events == "inline" or (args.events == "auto" and share >= 1e10)
+    r = run_timed(eng, args.steps, args.warmup, inline)
+    elapsed, wait_ms, waits, kernel_steps = r["elapsed"], r["wait_ms"], r["waits"], r["kernel_steps"]
+
+    out = None
+    if rank == 0:
+        cfg = eng.config
+        # sanity of the state the timed steps produced: this rank's own slice, without any collective (nothing after the
+        # timed region may stall the report)
+        p_own, _ = eng.download() if peer else eng.download_slice()
+        finite = bool(np.isfinite(p_own).all())
+        dtype = "f64" if args.fp64 else "f32"
+        pairs_per_step = float(n) * float(n)
+        value = pairs_per_step * args.steps / elapsed / 1e9
+        run_cfg = {"n": n, "dtype": dtype, "n_gpus": world, "variant": cfg["variant"], "iblock": cfg["iblock"], "nseg": cfg["nseg"],
+                   "sum_order": cfg["sum_order"], "sum_block": cfg["sum_block"], "launches_per_step": cfg["launches_per_step"],
+                   "wsplit": cfg["wsplit"], "isa_phase": cfg["isa_phase"], "long_buffers": cfg["long_buffers"], "xcd_map": cfg["xcd_map"],
+                   "kernel_source_sha": kernel_source_sha()}
+        roof = roofline_of(eng, cfg, r, n, args.fp64, args.steps, inline)
         pj = matching_pmc(run_cfg)
         if pj:
             roof["traffic"] = pj.get("hbm_bytes_per_launch")
@@ -601,18 +763,94 @@ def main(argv=None):
         if world > 1:
             out["comm_exposed_ms_per_step"] = round(wait_ms / max(1, kernel_steps), 4)
             out["comm_waits_per_step"] = round(waits / max(1, kernel_steps), 2)
-    eng.close()
+            out["transport_used"] = "peer" if peer else ("rccl" if transport == "rccl" else "host")
+    extras = want_forms or want_c5
+    if eng is not None and not extras:
+        eng.close()
     if rank == 0:
         if not args.no_cpu_baseline:
-            # after the timed region and with the GPU context closed; the other ranks wait at the barrier below, idle
+            # after the timed region (one GPU: with the GPU context closed); the other ranks wait at the barrier below, idle
             try:
                 out["cpu_baseline"] = cpu_baseline(n, args.seed, args.fp64)
             except Exception as e:    # the GPU result is reported in any case
                 out["cpu_baseline"] = {"value": None, "unit": "billion pair-interactions/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), flush=True)            # THE HEADLINE LINE — out before any extra is attempted
+    barrier()
+    if extras:
+        ex = {}
+        if want_forms:
+            ex["comm_forms"] = comm_forms_pass(eng, nb, args, world, n, transport, run_timed)
+        if eng is not None:
+            eng.close()
+        if want_c5:
+            try:
+                ex["config5"] = config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_of, np)
+            except Exception as e:      # (a rank that fails here leaves the others in a collective: the supervisor's extras deadline ends that)
+                ex["config5"] = {"error": repr(e)}
+                raise
+        if rank == 0:
+            out.update(ex)
+            print(json.dumps(out), flush=True)        # headline + extras: the line the supervisor prefers
         barrier()
+    if world > 1:
         dist.destroy_process_group()
+
+
+def comm_forms_pass(eng, nb, args, world, n, transport, run_timed, steps=3):
+    """SURVEY.md §8(f) rank 4 measured where it can be: three steps each of the north_star's ring (P-1 dependent groups, one
+    force launch per arriving slice), the DIRECT group (one hop over all links) and ncclAllGather, same engine, same state.
+    Transports without forms (peer copies, host-staged) give one entry.  Every rank takes part (eng None: collectives only)."""
+    if transport == "rccl":
+        forms = [("ring", nb.COMM_RING, 2), ("direct", nb.COMM_DIRECT, 1), ("allgather", nb.COMM_ALLGATHER, 1)]
+    else:
+        forms = [("peer" if transport.startswith("peer") else "host", None, args.overlap)]
+    res = {}
+    for name, comm, overlap in forms:
+        if eng is not None and comm is not None:
+            eng.set_option(nb.OPT_COMM, comm)
+            eng.set_option(nb.OPT_OVERLAP, overlap)
+        r = run_timed(eng, steps, 1, True)
+        entry = {"ms_per_step": round(1e3 * r["elapsed"] / steps, 3), "comm_exposed_ms_per_step": round(r["wait_ms"] / steps, 4),
+                 "value": round(float(n) * float(n) * steps / r["elapsed"] / 1e9, 2), "overlap": overlap, "steps": steps}
+        if eng is not None and comm is not None:
+            entry["form_resolved"] = COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?")     # allgather needs equal slices: ring otherwise
+        res[name] = entry
+    if eng is not None and transport == "rccl":
+        eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER, "direct": nb.COMM_DIRECT}[args.comm])
+        eng.set_option(nb.OPT_OVERLAP, args.overlap)
+    return res
+
+
+def config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_of, np, steps=2):
+    """BASELINE configs[4]: N = 4,194,304 fp64 sharded over the job's GPUs, 1 warm-up + 2 timed steps, in the engine's own
+    configuration.  "HBM GB/s vs peak" (the config's own words) = the algorithmic bytes of a step — 128 B per owned body: its
+    position and velocity read and written — over the step time; the path stays VALU-bound."""
+    n5 = args.config5_bodies
+    e5 = open_engine(n5, True)
+    try:
+        if e5 is not None:
+            pos, vel = nb.make_bodies(n5, seed=args.seed, dtype=np.float64)
+            e5.upload(pos, vel)
+            del pos, vel
+        r = run_timed(e5, steps, 1, True)
+        res = None
+        if rank == 0:
+            cfg = e5.config
+            roof = roofline_of(e5, cfg, r, n5, True, steps, True)
+            ms = 1e3 * r["elapsed"] / steps
+            bytes_per_step = cfg["n_local"] * 128.0
+            res = {"workload": "N=%d fp64 over %d GPU(s), %d timed steps" % (n5, world, steps),
+                   "value": round(float(n5) * float(n5) * steps / r["elapsed"] / 1e9, 2), "unit": "billion pair-interactions/s",
+                   "ms_per_step": round(ms, 3),
+                   "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_avg", "kernel_launches", "frac_of_issue_bound")},
+                   "hbm_gb_per_s": round(bytes_per_step / (ms * 1e-3) / 1e9, 3), "hbm_frac_of_peak": round(bytes_per_step / (ms * 1e-3) / 8e12, 7),
+                   "hbm_note": "algorithmic bytes per GPU and step (128 B per owned body) over the step time; peak 8 TB/s",
+                   "comm_exposed_ms_per_step": round(r["wait_ms"] / steps, 4),
+                   "kernel": {k: cfg[k] for k in ("variant", "nseg", "wsplit", "launches_per_step", "n_local")}}
+        return res
+    finally:
+        if e5 is not None:
+            e5.close()
 
 
 if __name__ == "__main__":

@@ -14,6 +14,15 @@ order — include/nbody.h NBODY_SUM_BLOCKED / oracle/nbody_ref.h ref_order_t.  W
 waves of a workgroup) a segment is first cut into 4 pieces of ceil(len / 4) sources, each summed as above on its own, and
 the piece sums are added in ascending order to give the segment's sum (a third level).
 
+The RTL-faithful mode (round 4: `rtl_*.json`): d2 with the RTL's own five roundings — dx*dx and dy*dy rounded, their sum
+rounded (S/dxy.vhd:113-122), fma(dz, dz, eps) rounded once (S/dzsoft.vhd:201-202), the two joined by one add
+(S/dxyz_soft.vhd:149-150) — and the RTL's summation over ONE stream of all N sources (S/top_level.vhd:233-254): partial k
+accumulates the sources j = k mod 16 from 0.0 with one fma each (the fma's 16-deep feedback, S/fxyz.vhd:120-145), the
+16 in-flight sums are latched rotated, results(t) = partial (n + t) mod 16, or 0.0 where that slot never received an item
+(n < 16) (S/fxyz.vhd:147-184; the rotation is what tests/test_fpga_scatter_model.py derives from the control logic), and
+joined by the pairwise adder tree ((r0+r1)+(r2+r3))+... (S/final_adder.vhd:88-104).  This is what the engine runs with
+NBODY_ARITH_REFERENCE_STRICT + NBODY_SUM_FPGA16 + one segment, and what nbody_mailbox_run returns in that mode.
+
 Inputs are generated here with the repository's seeded generator formula restated (SplitMix64 -> uniform [-1, 1)),
 and are stored in the fixture as hex words, so consumers need nothing but the JSON.
 Run:  python tests/golden/make_system.py      (about a minute)
@@ -143,8 +152,41 @@ def forces(pos, nslices, sub, block, wsplit=1):
     return out
 
 
-def step(pos, vel, dt, nslices, sub, block, wsplit=1):
-    f = forces(pos, nslices, sub, block, wsplit)
+def d2_reference(dx, dy, dz, soft):
+    """the RTL's own rounding points for the softened squared distance"""
+    sxy = add(mul(dx, dx), mul(dy, dy))      # S/dxy.vhd:113-122: two products rounded, then their sum
+    sz = fma(dz, dz, soft)                   # S/dzsoft.vhd:201-202: fused, one rounding
+    return add(sxy, sz)                      # S/dxyz_soft.vhd:149-150
+
+
+def tree16(r):
+    """S/final_adder.vhd:88-104: four levels of pairwise adds over 16 leaves"""
+    while len(r) > 1:
+        r = [add(r[2 * k], r[2 * k + 1]) for k in range(len(r) // 2)]
+    return r[0]
+
+
+def forces_rtl(pos):
+    """every body against ONE stream of all n sources in the RTL's order (module docstring)"""
+    soft = bits_f32(SOFT_BITS)
+    n = len(pos)
+    out = []
+    for i in range(n):
+        xi, yi, zi = pos[i][0], pos[i][1], pos[i][2]
+        part = [[0.0, 0.0, 0.0] for _ in range(16)]
+        for j in range(n):                                               # S/top_level.vhd:233-254: all sources, self included, ascending
+            dx, dy, dz = add(pos[j][0], -xi), add(pos[j][1], -yi), add(pos[j][2], -zi)     # S/dxy.vhd:94-98: target - this
+            inv = rsqrt(d2_reference(dx, dy, dz, soft))
+            inv3 = mul(inv, mul(inv, inv))                               # S/cube.vhd:66-70
+            k = j % 16                                                   # S/fxyz.vhd:129-145
+            part[k] = [fma(dx, inv3, part[k][0]), fma(dy, inv3, part[k][1]), fma(dz, inv3, part[k][2])]
+        res = [part[(n + t) % 16] if n - 16 + t >= 0 else [0.0, 0.0, 0.0] for t in range(16)]   # S/fxyz.vhd:147-184
+        out.append([tree16([res[t][c] for t in range(16)]) for c in range(3)] + [0.0])
+    return out
+
+
+def step(pos, vel, dt, nslices, sub, block, wsplit=1, rtl=False):
+    f = forces_rtl(pos) if rtl else forces(pos, nslices, sub, block, wsplit)
     vel = [[fma(dt, f[i][c], vel[i][c]) for c in range(3)] + [vel[i][3]] for i in range(len(pos))]
     pos = [[fma(vel[i][c], dt, pos[i][c]) for c in range(3)] + [pos[i][3]] for i in range(len(pos))]
     return pos, vel, f
@@ -172,9 +214,28 @@ def make(name, n, seed, steps, nslices, sub, block, wsplit=1):
     print("wrote", name)
 
 
+def make_rtl(name, n, seed, steps):
+    pos, vel = uniform_words(n, seed)
+    dt = bits_f32(f32_bits(0.01))
+    fx = {"n": n, "seed": seed, "steps": steps, "dt_bits": "%08x" % f32_bits(dt),
+          "order": {"summ": "fpga16", "d2": "reference", "nslices": 1, "sub": 1},
+          "arith": "d2 = ((dx*dx)+(dy*dy)) + fma(dz,dz,eps), inv = (float)(1.0/sqrt((double)d2)), inv3 = inv*(inv*inv), "
+                   "partial[j mod 16] = fma(d, inv3, partial[j mod 16]), F = tree16(partial rotated by n mod 16)",
+          "pos0": hexwords(pos), "vel0": hexwords(vel)}
+    p, v = pos, vel
+    for s in range(steps):
+        p, v, f = step(p, v, dt, 1, 1, 0, rtl=True)
+        if s == 0:
+            fx["forces0"] = hexwords(f)
+    fx["pos"] = hexwords(p)
+    fx["vel"] = hexwords(v)
+    json.dump(fx, open(os.path.join(HERE, name), "w"), indent=0)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
     import sys
-    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # "wsplit" / "wsplit16": only those fixtures (the others are unchanged)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # "wsplit" / "wsplit16" / "rtl": only those fixtures (the others are unchanged)
     if which == "all":
         make("system_n64_seq.json", 64, 42, 10, 1, 1, 0)           # the plain sequential sum, 10 steps (BASELINE config 1's loop, tiny)
         make("system_n200_blocked.json", 200, 7, 3, 1, 3, 64)      # 3 segments of 67/67/66 sources, blocks of 64 + a remainder
@@ -182,5 +243,9 @@ if __name__ == "__main__":
     if which in ("all", "wsplit"):
         make("system_n560_wsplit4.json", 560, 5, 2, 1, 2, 64, wsplit=4)        # 2 segments of 280 = 4 pieces of 70: a block fold + 6 in each
         make("system_n90_wsplit4_sharded.json", 90, 3, 3, 3, 2, 64, wsplit=4)  # 3 rank slices x 2 segments of 15 = pieces of 4, 4, 4, 3
+    if which in ("all", "rtl"):
+        make_rtl("rtl_n9.json", 9, 11, 2)        # fewer than 16 sources: seven result slots never receive an item
+        make_rtl("rtl_n40.json", 40, 12, 2)      # n mod 16 = 8
+        make_rtl("rtl_n100.json", 100, 13, 2)    # n mod 16 = 4
     if which in ("all", "wsplit16"):
         make("system_n130_wsplit16.json", 130, 2, 2, 1, 1, 64, wsplit=16)      # one segment, 16 pieces: 14 of 9 sources, one of 4, one empty

@@ -22,23 +22,35 @@ STUB = textwrap.dedent('''
     mode = os.environ.get("STUB_MODE", "ok")
     assert os.environ["NBODY_BENCH_WORKER"] == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1"
     assert "TORCHELASTIC_USE_AGENT_STORE" not in os.environ and "OMP_NUM_THREADS" not in os.environ
+    open(os.environ["NBODY_BENCH_IMPORTED_FILE"], "w").close()      # "import torch has returned"
     if transport not in ("host", "peer") or (transport == "peer" and mode.endswith("twice")):
         mode = mode.replace("twice", "")
         if mode == "fail" and rank == world - 1:
             sys.stderr.write("RCCL error 5 near nbody_hip.hip:123\\n")
             sys.exit(3)
-        if mode == "hang" and rank == 0:
-            time.sleep(3600)
-        if mode == "hang":
-            time.sleep(3600)      # the others wait for rank 0 in a collective
+        if mode in ("hang", "fail"):
+            time.sleep(3600)      # a hang; or the others wait in a collective for the rank that died
     if os.environ.get("NBODY_BENCH_READY_FILE") and mode != "noready":
         open(os.environ["NBODY_BENCH_READY_FILE"], "w").close()
     if mode == "noready" and transport not in ("host", "peer"):
         time.sleep(3600)
+    line = {"metric": "stub", "n_gpus": world, "config": {"comm": "allgather / %s / overlap 1" % {"host": "host-staged", "peer": "peer copies"}.get(transport, "rccl")},
+            "env": {k: os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}, "argv": sys.argv[1:]}
     if rank == 0:
         print("noise before the line")
-        print(json.dumps({"metric": "stub", "n_gpus": world, "config": {"comm": "allgather / %s / overlap 1" % {"host": "host-staged", "peer": "peer copies"}.get(transport, "rccl")},
-                          "env": {k: os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}, "argv": sys.argv[1:]}))
+        print(json.dumps(line), flush=True)
+    # the extras pass: after the headline line, in the same processes
+    if mode == "extrashang":
+        time.sleep(3600)
+    if mode == "extrascrash" and rank == world - 1:
+        sys.stderr.write("HIP error 719 in the extras pass\\n")
+        sys.exit(5)
+    if mode == "extrascrash":
+        time.sleep(3600)          # the others sit in the collective the crashed rank never joins
+    if mode == "extras" and rank == 0:
+        time.sleep(0.3)
+        line["comm_forms"] = {"ring": {"ms_per_step": 31.0}, "direct": {"ms_per_step": 30.0}, "allgather": {"ms_per_step": 30.5}}
+        print(json.dumps(line), flush=True)
 ''')
 
 
@@ -170,3 +182,94 @@ def test_sigterm_to_the_supervisor_ends_the_workers(tmp_path):
         while time.time() - t0 < 15 and any(alive(q) for q in pids):
             time.sleep(0.1)
         assert not any(alive(q) for q in pids), "workers survived %s of their supervisor" % sig
+
+
+# ---- round 4: the extras pass, the time budget, machine-readable fallback fields -------------------------------------------
+
+def test_extras_line_is_preferred_when_the_extras_finish(stub):
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extras_s=30, extra_env={"STUB_MODE": "extras"})
+    assert code == 0 and set(obj["comm_forms"]) == {"ring", "direct", "allgather"} and "extras" not in obj
+    assert obj["transport_used"] == "rccl" and obj["fallback_from"] is None and obj["fallback_reason"] is None
+    assert [a["transport"] for a in obj["attempts"]] == ["rccl"] and obj["attempts"][0]["result"] == "ok"
+
+
+@pytest.mark.parametrize("mode,what", [("extrashang", "timed out"), ("extrascrash", "failed: worker exited with code 5")])
+def test_extras_that_hang_or_crash_keep_the_headline(stub, mode, what):
+    """the headline line is out before any extra is attempted: a hang in the extras is killed at ITS deadline (not the
+    attempt's), a crash ends it at once, and either way the first line is returned with exit code 0 and no retry"""
+    import time
+    t0 = time.time()
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=600, extras_s=1.5, extra_env={"STUB_MODE": mode})
+    assert code == 0 and time.time() - t0 < 60
+    assert obj["metric"] == "stub" and obj["extras"].startswith(what) and "comm_forms" not in obj
+    assert obj["transport_used"] == "rccl" and len(obj["attempts"]) == 1 and obj["attempts"][0]["extras"].startswith(what)
+    if mode == "extrascrash":
+        assert "HIP error 719" in obj["extras"]
+
+
+@pytest.mark.parametrize("shape", ["bare", "per-rank"])
+def test_extras_hang_under_one_supervisor_per_rank(stub, tmp_path, shape):
+    """the torch.distributed.run shape: only the lead sees rank 0's stdout; the others learn of the headline through the marker"""
+    if shape == "bare":
+        pytest.skip("covered above")
+    rdzv = tmp_path / "rdzv"
+    rdzv.mkdir()
+    res = {}
+
+    def run(rank):
+        res[rank] = bench.supervise(stub, 3, [rank], "auto", deadline_s=600, extras_s=1.5, rdzv_dir=str(rdzv), extra_env={"STUB_MODE": "extrashang"})
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert all(res[r][0] == 0 for r in range(3)), res
+    assert res[0][1]["metric"] == "stub" and res[0][1]["extras"].startswith("timed out")
+
+
+def test_hang_in_a_timed_step_leaves_room_for_the_fallback(stub):
+    """one budget for the whole command: attempt 0's deadline = budget - reserve for the attempts still to come"""
+    import time
+    t0 = time.time()
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=600, budget_s=8.0, warm_import_s=0.5, reserve_s=1.5, min_attempt_s=0.5,
+                                min_start_s=1.0, extra_env={"STUB_MODE": "hang"})
+    took = time.time() - t0
+    assert code == 0 and took < 8.0 + 6.0, took                      # (+ the kill grace of the hung group)
+    assert obj["transport_used"] == "peer" and obj["fallback_from"] == "rccl" and obj["fallback_reason"].startswith("timed out after 5 s")
+    assert [a["transport"] for a in obj["attempts"]] == ["rccl", "peer"]
+    assert 3.5 <= obj["attempts"][0]["seconds"] <= 7.0 and obj["attempts"][0]["result"].startswith("timed out")
+    assert obj["attempts"][1]["result"] == "ok" and "rccl attempt: timed out" in obj["config"]["comm"]
+
+
+def test_hang_at_start_up_is_noticed_soon_after_the_import(stub):
+    """two-stage readiness: `import torch` returned, but the transport is not up ready_after_import_s later"""
+    import time
+    t0 = time.time()
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=600, startup_s=300, ready_after_import_s=1.0, budget_s=540,
+                                extra_env={"STUB_MODE": "noready"})
+    assert code == 0 and time.time() - t0 < 30
+    assert obj["transport_used"] == "peer" and "transport not up 1 s after `import torch` returned" in obj["fallback_reason"]
+    assert obj["attempts"][0]["import_s"] is not None and obj["attempts"][0]["seconds"] < 15
+
+
+def test_no_fallback_turns_a_failed_transport_into_exit_code_3(stub):
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, no_fallback=True, extra_env={"STUB_MODE": "fail"})
+    assert code == bench.EXIT_NO_FALLBACK == 3 and obj is None
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, no_fallback=True, extra_env={"STUB_MODE": "ok"})
+    assert code == 0 and obj["transport_used"] == "rccl"
+
+
+def test_the_fallback_label_names_the_transport_that_was_tried_first(stub):
+    """--transport peer that fails falls back to host, and the text says "peer attempt", not "rccl attempt" """
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "peer", deadline_s=60, extra_env={"STUB_MODE": "failtwice"})
+    assert code == 0 and obj["transport_used"] == "host" and obj["fallback_from"] == "peer"
+    assert "(peer attempt: worker exited with code 3" in obj["config"]["comm"]
+
+
+def test_budget_spent_before_a_fallback_starts():
+    """nothing is started with less than 20 s of the budget left"""
+    import time
+    code, obj = bench.supervise([sys.executable, "-c", "import time; time.sleep(3600)"], 2, [0, 1], "auto", deadline_s=600, budget_s=21.5,
+                                warm_import_s=0.0, reserve_s=9.5, min_attempt_s=0.5, t_start=time.time())
+    assert code == 1 and obj is None      # attempt 0: 21.5 - 2 x 9.5 = 2.5 s; then < 20 s are left: peer and host are not started

@@ -121,3 +121,67 @@ def test_virtual_ranks_reproduce_the_sharded_fixture(nb, monkeypatch, name):
             assert np.array_equal(bits(p), bits(fx["pos"])) and np.array_equal(bits(v), bits(fx["vel"])), overlap
         finally:
             eng.close()
+
+
+# ---- the RTL-faithful mode (round 4): the reference's own five roundings for d2 and its own summation — 16 interleaved
+# partial sums per axis over ONE stream of all N sources, latched rotated, joined by the adder tree — pinned by the third
+# statement (tests/golden/make_system.py forces_rtl: exact rationals, no code shared with oracle or kernels)
+RTL_FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "rtl_*.json")))
+
+
+def test_rtl_fixtures_present():
+    ns = sorted(json.load(open(f))["n"] for f in RTL_FIXTURES)
+    assert ns == [9, 40, 100]                       # below 16 (empty result slots), and two with n mod 16 != 0
+    assert all(json.load(open(f))["order"] == {"summ": "fpga16", "d2": "reference", "nslices": 1, "sub": 1} for f in RTL_FIXTURES)
+
+
+@pytest.mark.parametrize("path", RTL_FIXTURES, ids=[os.path.basename(p) for p in RTL_FIXTURES])
+def test_oracle_reproduces_the_rtl_fixture(nb, oracle, oracle_fast, path):
+    fx = load(path)
+    pos, vel = nb.make_bodies(fx["n"], seed=fx["seed"])
+    assert np.array_equal(bits(pos), bits(fx["pos0"])) and np.array_equal(bits(vel), bits(fx["vel0"]))
+    for ora in (oracle, oracle_fast):
+        f = ora.forces_f32(fx["pos0"], d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
+        assert np.array_equal(bits(f), bits(fx["forces0"]))
+        p, v = fx["pos0"].copy(), fx["vel0"].copy()
+        ora.step(p, v, fx["dt"], fx["steps"], d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
+        assert np.array_equal(bits(p), bits(fx["pos"])) and np.array_equal(bits(v), bits(fx["vel"]))
+        # and the fma-contracted d2 of the timed kernels is a DIFFERENT function: the fixture distinguishes the two modes
+        g = ora.forces_f32(fx["pos0"], d2=O.D2_FMA3, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
+        assert not np.array_equal(bits(g), bits(fx["forces0"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", RTL_FIXTURES, ids=[os.path.basename(p) for p in RTL_FIXTURES])
+def test_engine_and_mailbox_reproduce_the_rtl_fixture(nb, path):
+    """NBODY_ARITH_REFERENCE_STRICT + NBODY_SUM_FPGA16 + one segment — the three options INTEGRATION.md §1 lists as "RTL-faithful
+    result" — through nbody_forces, through the reference's own RAM images (nbody_mailbox_run) and through the step loop:
+    bit for bit the third statement's answer, no oracle in the loop"""
+    fx = load(path)
+    eng = nb.NBody(fx["n"])
+    try:
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_REFERENCE_STRICT)
+        eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_FPGA16)
+        eng.set_option(nb.OPT_JSUB, 1)
+        assert eng.config["nseg"] == 1 and eng.config["sum_order"] == "fpga16"
+        assert np.array_equal(bits(eng.forces(fx["pos0"])), bits(fx["forces0"]))
+        ram_a = nb.mailbox.encode_request(fx["pos0"])
+        ram_b = nb.mailbox.run(eng, ram_a, clock_khz=300000)
+        assert nb.mailbox.decode_control(ram_a)["begin"] == 0
+        assert np.array_equal(bits(ram_b), bits(fx["forces0"])) and np.all(ram_b[:, 3] == 0)
+        for fuse in (1, 0):
+            eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+            eng.upload(fx["pos0"], fx["vel0"])
+            eng.step(fx["dt"], fx["steps"])
+            p, v = eng.download()
+            assert np.array_equal(bits(p), bits(fx["pos"])) and np.array_equal(bits(v), bits(fx["vel"])), fuse
+        # the mailbox with the context's DEFAULT options is the timed arithmetic (fma-contracted d2, v_rsq_f32, blocked sums):
+        # within tolerance of the RTL-faithful answer, not equal to it — which is why INTEGRATION.md names the three options
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
+        eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED)
+        eng.set_option(nb.OPT_JSUB, 0)
+        fast = nb.mailbox.run(eng, nb.mailbox.encode_request(fx["pos0"]))
+        d = np.abs(fast[:, :3].astype(np.float64) - fx["forces0"][:, :3]).max() / np.abs(fx["forces0"][:, :3]).max()
+        assert 0 < d < 1e-5
+    finally:
+        eng.close()

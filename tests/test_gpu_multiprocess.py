@@ -106,6 +106,23 @@ def test_bench_launches_and_supervises_its_own_workers(tmp_path):
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
     assert "peer copies" in out["config"]["comm"] and "rccl attempt:" in out["config"]["comm"] and "RCCL error" in out["config"]["comm"]
     assert out["comm_exposed_ms_per_step"] >= 0 and out["config"]["kernel"]["nranks"] == 2
+    # machine-readable account of what ran: a scaling driver must not take this for the RCCL point
+    assert out["transport_used"] == "peer" and out["fallback_from"] == "rccl" and "RCCL error" in out["fallback_reason"]
+    assert [a["transport"] for a in out["attempts"]] == ["rccl", "peer"] and out["attempts"][1]["result"] == "ok"
+    assert out["attempts"][0]["import_s"] is not None and out["supervisor_seconds"] > 0
+    # the extras pass ran in the same workers after the headline line: one entry for a transport that has no forms
+    assert set(out["comm_forms"]) == {"peer"} and out["comm_forms"]["peer"]["ms_per_step"] > 0 and "extras" not in out
+    assert "config5" not in out          # BASELINE configs[4] is an 8-GPU configuration: only there (or with --extras all)
+
+
+def test_bench_no_fallback_exit_code(tmp_path):
+    """--no-fallback: RCCL refuses the second rank on the one device -> exit code 3, no line, no retry on peer copies"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NBODY_OVERSUBSCRIBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "65536", "--steps", "2", "--no-fallback",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 3, r.stdout[-2000:] + r.stderr[-3000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")] and "attempt 1" not in r.stderr
 
 
 def test_bench_peer_copy_transport(tmp_path):
@@ -115,10 +132,17 @@ def test_bench_peer_copy_transport(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["NBODY_OVERSUBSCRIBE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "262144", "--steps", "3", "--warmup", "1",
-                        "--transport", "peer", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--transport", "peer", "--no-cpu-baseline", "--extras", "all", "--config5-bodies", "65536"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["finite"]
     assert "hipMemcpyPeerAsync" in out["config"]["comm"] and "one process driving all 2 GPUs" in out["config"]["comm"]
     assert out["config"]["kernel"]["nranks"] == 2 and out["config"]["kernel"]["launches_per_step"] == 2
     assert out["roofline"]["kernel_launches"] == 2 * 3 and 0 < out["roofline"]["frac"] < 1
+    assert out["transport_used"] == "peer" and out["fallback_from"] is None and len(out["attempts"]) == 1
+    # --extras all: the transfer "forms" of this transport (one) and the fp64 configuration (here at 65536 bodies), after the headline
+    assert set(out["comm_forms"]) == {"peer"} and "extras" not in out
+    c5 = out["config5"]
+    assert c5["value"] > 0 and 0 < c5["roofline"]["frac"] < 1 and c5["roofline"]["peak"] == 78.6 and c5["hbm_gb_per_s"] > 0
+    assert c5["kernel"]["n_local"] == 32768 and c5["comm_exposed_ms_per_step"] >= 0
