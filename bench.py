@@ -35,7 +35,7 @@ past it the workers are killed and the FIRST line is returned with "extras": "ti
 
 Rank 0 prints ONE JSON line, always with:
   roofline      the force kernel priced at 20 flop per pair against the fp32 (157.3 TFLOP/s) or
-                fp64 (78.6) VECTOR peak — the path has no contraction for the matrix cores — with the kernel's
+                fp64 (78.6: measured v_fma_f64 issue rate, profiles/r01_microbench_valu_issue.txt) VECTOR peak — no contraction for the matrix cores — with the kernel's
                 duration measured live by HIP events on the library's compute stream; beside it the instruction-issue
                 bound (30 cycles per wave-pair in fp32, 80 in fp64) and cycles per wave-pair.  `traffic` and the
                 other *_pmc fields come from the committed rocprofv3 passes of THIS configuration
@@ -65,7 +65,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FLOP_PER_PAIR = 20                # SURVEY.md §8(d) convention (literal count: 18)
-PEAK_VECTOR_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 (32) flop/clk x 2.4 GHz
+# fp32: MI355X_MICROARCH.md "Peak FP32 (vector) 157.3 TFLOPS" = 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz.
+# fp64: the guide states NO fp64 vector figure; 78.6 is this repository's own measurement — v_fma_f64 issues at 4.0 cycles per wave64
+# on a SIMD (profiles/r01_microbench_valu_issue.txt: v_fma_f64 / v_mul_f64 W=4, W=8), i.e. 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
+PEAK_VECTOR_TFLOPS = {"f32": 157.3, "f64": 78.6}
 # cycles of VALU issue per wave64 pair: fp32 11 x 2 + 8 (v_rsq_f32); fp64 16 x 4 + 16 (v_rsq_f64)
 # measured: profiles/r01_microbench_valu_issue.txt, DESIGN.md §3
 ISSUE_CYCLES_PER_WAVE_PAIR = {"f32": 30, "f64": 80}

@@ -68,8 +68,9 @@ enum {
   NBODY_OPT_FUSE_COMBINE = 14, /* 1: the segments' partial sums are added by the last wave to arrive, inside the force launch (one
                               launch per step); 0: a separate combine kernel; -1 (default): one launch when the launch has
                               >= 4 workgroups per CU, where the hand-off hides behind other workgroups, else two.  Same bits. */
-  NBODY_OPT_GRAPH = 12,    /* nbody_step on one GPU replays a captured HIP graph of an even number of steps: 1 (default) = 8 steps per graph
-                              once a call brings 16, else 2; k >= 2 = k steps per graph; 0: launch every kernel */
+  NBODY_OPT_GRAPH = 12,    /* nbody_step on one GPU replays a captured HIP graph of an even number of steps: 1 (default) = 32 steps per graph
+                              when the call brings >= 64 (after the engine's first, eagerly launched step), 16 from 32, 8 from 16, else 2;
+                              k >= 2 = k steps per graph (rounded down to even); 0: launch every kernel.  Same bits in every case. */
   NBODY_OPT_WAVES_PER_SIMD = 11, /* cap the force kernel's occupancy at k waves per SIMD (0 = no cap): tuning knob */
   NBODY_OPT_WSPLIT = 17,   /* 4 / 16: a workgroup owns 64 bodies and its 4 / 16 waves walk one piece of the source segment each; the
                               sums are added through LDS in ascending source order (a third level of the sum, like the reference's

@@ -367,7 +367,10 @@ int launch_timed(Local& L, K kernel, dim3 grid, const ForceArgs& a) {
   size_t dyn_lds = 0;
   if (g.opt.waves_per_simd > 0 && g.opt.waves_per_simd < 8) {
     const size_t static_lds = (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0) + (a.wsplit > 1 ? (size_t)(a.wsplit - 1) * 64 * word_bytes() : 0);
-    dyn_lds = (size_t)(160 * 1024) / (size_t)g.opt.waves_per_simd - 512 - static_lds;
+    // (a workgroup of WS waves holds WS / 4 wave slots per SIMD: the cap is on workgroups per CU = waves_per_simd / (WS / 4))
+    const size_t budget = (size_t)(160 * 1024) / (size_t)g.opt.waves_per_simd;
+    if (static_lds + 512 > budget) return NBODY_ERR_ARG;   // the kernel's own LDS (16-wave fp64 join: 30 KiB) already exceeds that share: no such cap exists
+    dyn_lds = budget - 512 - static_lds;
     if (dyn_lds > 64 * 1024) HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(kernel, grid, dim3(wg_threads(a.wsplit)), dyn_lds, L.compute, a);

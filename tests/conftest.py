@@ -20,12 +20,12 @@ def pytest_sessionstart(session):
     import subprocess
     need = [os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"),
             os.path.join(ROOT, "oracle", "libnbody_ref.so"), os.path.join(ROOT, "oracle", "libnbody_ref_fast.so"),
-            os.path.join(ROOT, "oracle", "nbody_cpu")]
+            os.path.join(ROOT, "oracle", "nbody_cpu"), os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip_diag.so")]
     if all(os.path.exists(p) for p in need):
         return
-    r = subprocess.run(["make", "lib", "host", "oracle"], cwd=ROOT, capture_output=True, text=True)
+    r = subprocess.run(["make", "lib", "diag", "host", "oracle"], cwd=ROOT, capture_output=True, text=True)
     if r.returncode != 0:
-        raise pytest.UsageError("`make lib host oracle` failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+        raise pytest.UsageError("`make lib diag host oracle` failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,68 @@
+"""The fp64 path against a checked fixture (tests/golden/fp64_n64.json, made by tests/golden/make_fp64.py: the force sum
+evaluated in 60-digit decimal arithmetic and rounded once to binary64 — no code shared with the oracle or the kernels).
+
+There is no strict fp64 mode (1/sqrt is v_rsq_f64 + one third-order step, a few ulp), so the bar is a bound, written here:
+every row's force within 16 ulp of that row's largest component.  What a correctly rounded evaluation in sequential order
+costs is measured beside it (the oracle: 7 ulp worst row, 2 median at N = 64) — the bound is twice that, far below what a
+missing, doubled or misplaced source would do (a single term is ~2^52 ulp), in every segmentation the engine can take."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BOUND_ULP = 16.0
+
+
+def load():
+    fx = json.load(open(os.path.join(HERE, "golden", "fp64_n64.json")))
+    w = lambda k: np.array([int(h, 16) for h in fx[k]], np.uint64).view(np.float64).reshape(-1, 4)   # noqa: E731
+    return fx, w("pos0"), w("forces0")
+
+
+def row_ulps(got, want):
+    ulp = np.spacing(np.abs(want[:, :3]).max(1))
+    return np.abs(got[:, :3] - want[:, :3]).max(1) / ulp
+
+
+def test_fixture_inputs_are_full_width_doubles(nb):
+    fx, pos, f = load()
+    p1, _ = nb.make_bodies(fx["n"], seed=fx["seed"], dtype=np.float64)
+    p2, _ = nb.make_bodies(fx["n"], seed=fx["seed"] + 1, dtype=np.float64)
+    want = p1 + p2 * 2.0 ** -25
+    assert np.array_equal(pos[:, :3], want[:, :3]) and np.all(pos[:, 3] == 1.0)
+    assert (pos[:, :3].view(np.uint64) & np.uint64(0x1FFFFFFF)).any()         # the low 29 bits of the significand are in use
+    assert np.isfinite(f).all() and np.all(f[:, 3] == 0)
+
+
+def test_oracle_fp64_within_bound(oracle, oracle_fast):
+    fx, pos, f = load()
+    for ora in (oracle, oracle_fast):
+        e = row_ulps(ora.forces_f64(pos), f)
+        assert e.max() <= 8.0, e.max()          # sequential order, IEEE sqrt and divide: measured 7.0 worst, 2.0 median
+
+
+@pytest.mark.gpu
+def test_engine_fp64_within_bound_in_every_segmentation(nb, capsys):
+    """the engine's own configuration, the three wave splits and two explicit segmentations, both delivery kernels"""
+    fx, pos, f = load()
+    eng = nb.NBody(fx["n"], fp64=True)
+    seen = []
+    try:
+        for variant in (nb.VARIANT_AUTO, nb.VARIANT_SMEM):
+            for wsplit in (-1, 1, 4, 16):
+                for jsub in (0, 1, 3):
+                    eng.set_option(nb.OPT_VARIANT, variant)
+                    eng.set_option(nb.OPT_WSPLIT, wsplit)
+                    eng.set_option(nb.OPT_JSUB, jsub)
+                    cfg = eng.config
+                    e = row_ulps(eng.forces(pos), f)
+                    seen.append((cfg["variant"], cfg["wsplit"], cfg["nseg"], float(e.max()), float(np.median(e))))
+                    assert e.max() <= BOUND_ULP, seen[-1]
+        assert {s[1] for s in seen} == {1, 4, 16}
+    finally:
+        eng.close()
+    with capsys.disabled():
+        print("\n[fp64 fixture] worst row / median in ulp of the row's largest component: " +
+              "; ".join("%s W=%d nseg=%d: %.1f / %.1f" % s for s in seen[:12]))

@@ -111,3 +111,28 @@ def test_a_failed_step_does_not_poison_the_next_one(nb):
         assert np.array_equal(gv.view(np.uint32), v2[:half].view(np.uint32))
     finally:
         eng.close()
+
+
+def test_occupancy_cap_that_cannot_exist_is_refused_not_underflowed(nb):
+    """NBODY_OPT_WAVES_PER_SIMD caps the occupancy by giving each workgroup 160 KiB / k of dynamic LDS minus what the kernel holds
+    itself.  The 16-wave fp64 kernel's join already holds 30 KiB: with k = 7 that share is 22.9 KiB and the subtraction used to
+    wrap around into a 160-KiB request and an opaque HIP launch error.  Now: NBODY_ERR_ARG, the context stays usable,
+    and a cap that does exist changes no bit."""
+    n = 3000
+    pos, vel = nb.make_bodies(n, seed=4, dtype=np.float64)
+    eng = nb.NBody(n, fp64=True)
+    try:
+        eng.set_option(nb.OPT_WSPLIT, 16)
+        want = eng.forces(pos)
+        eng.set_option(nb.OPT_WAVES_PER_SIMD, 7)
+        with pytest.raises(nb.NBodyError) as e:
+            eng.forces(pos)
+        assert e.value.code == nb._lib.ERR_ARG
+        eng.set_option(nb.OPT_WAVES_PER_SIMD, 2)          # 80 KiB per workgroup: one 16-wave workgroup per CU
+        assert np.array_equal(eng.forces(pos).view(np.uint64), want.view(np.uint64))
+        eng.set_option(nb.OPT_WAVES_PER_SIMD, 0)
+        eng.upload(pos, vel)
+        eng.step(0.01, 3)                                  # and the step loop is intact after the refused launch
+        assert np.isfinite(eng.download()[0]).all()
+    finally:
+        eng.close()

@@ -1,0 +1,74 @@
+"""tools/results_table.py: the north_star's one table (absolute rate, % roofline, the 1/2/4/8 curve, host CPU) generated from the
+driver's records.  CPU only: the committed BENCH_r01..r03 / SCALE_r01..r03 records, plus a synthetic SCALE record of the shape a
+multi-GPU run will leave (headline lines for N = 1, 2, 4, 8; the N = 8 line carrying the extras)."""
+import importlib.util
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("results_table", os.path.join(ROOT, "tools", "results_table.py"))
+rt = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(rt)
+
+
+def line(n, value, **kw):
+    d = {"metric": "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofline", "value": value, "unit": "billion pair-interactions/s",
+         "n_gpus": n, "steps": 5, "dtype": "f32", "config": {"workload": "N=1048576 fp32 all-pairs softened gravity, leapfrog kick-drift, dt=0.01, seed 42"},
+         "roofline": {"frac": 0.59, "frac_of_issue_bound": 0.885}, "cpu_baseline": {"value": 60.0, "cores": 256}}
+    if n > 1:
+        d.update({"comm_exposed_ms_per_step": 0.02, "transport_used": "rccl", "fallback_from": None})
+    d.update(kw)
+    return d
+
+
+def test_committed_records_give_one_row_each():
+    recs = rt.records(ROOT)
+    names = [r[0] for r in recs]
+    for k in (1, 2, 3):
+        assert "BENCH_r%02d.json" % k in names and "SCALE_r%02d.json" % k in names
+    by = {r[0]: r for r in recs}
+    assert len(by["BENCH_r03.json"][2]) == 1 and by["BENCH_r03.json"][2][0]["value"] == 4614.52
+    assert by["SCALE_r03.json"][2] is None and "8-GPU" in by["SCALE_r03.json"][3]
+    t = rt.table(ROOT)
+    assert "| BENCH_r03.json | 1048576 | fp32 | 1 | 4615 | 58.7 | 88.0 |" in t and "55.6 (256 threads)" in t
+    assert "| SCALE_r03.json | — | — | — | not measured:" in t
+
+
+def test_scaling_record_with_extras(tmp_path):
+    for f in ("BENCH_r03.json",):
+        shutil.copy(os.path.join(ROOT, f), tmp_path / f)
+    extras = {"comm_forms": {"ring": {"ms_per_step": 31.2, "comm_exposed_ms_per_step": 1.25, "value": 35240.0, "overlap": 2},
+                             "direct": {"ms_per_step": 30.1, "comm_exposed_ms_per_step": 0.03, "value": 36530.0, "overlap": 1},
+                             "allgather": {"ms_per_step": 30.2, "comm_exposed_ms_per_step": 0.04, "value": 36400.0, "overlap": 1}},
+              "config5": {"workload": "N=4194304 fp64 over 8 GPU(s), 2 timed steps", "value": 14900.0, "ms_per_step": 1180.0,
+                          "roofline": {"frac": 0.474, "frac_of_issue_bound": 0.95}, "hbm_gb_per_s": 0.057, "hbm_frac_of_peak": 7.1e-6, "comm_exposed_ms_per_step": 0.1}}
+    scale = {"runs": [{"n": 1, "parsed": line(1, 4600.0)}, {"n": 2, "parsed": line(2, 9100.0)}, {"n": 4, "parsed": line(4, 18000.0)},
+                      {"n": 8, "parsed": line(8, 35500.0, **extras), "tail": json.dumps(line(8, 35500.0)) + "\n"}]}
+    json.dump(scale, open(tmp_path / "SCALE_r04.json", "w"))
+    t = rt.table(str(tmp_path))
+    rows = [r for r in t.splitlines() if r.startswith("| SCALE_r04.json")]
+    assert len(rows) == 4 + 3 + 1                                     # four headline lines (the raw copy of N = 8 de-duplicated), three forms, config 5
+    assert "| 8 | 35500 | 59.0 | 88.5 | 0.965 | 0.020 | rccl |" in t     # 35500 / (8 x 4600)
+    assert "| 2 | 9100 | 59.0 | 88.5 | 0.989 |" in t
+    assert "extras: NBODY_COMM_RING, overlap 2, 31.20 ms/step" in t and "| 1.250 |" in t
+    assert "| 4194304 | fp64 | 8 | 14900 | 47.4 | 95.0 |" in t and "BASELINE configs[4]" in t
+    # a fallback is visible in the table: a peer-copy number cannot pass for the RCCL point
+    json.dump({"parsed": line(8, 30000.0, transport_used="peer", fallback_from="rccl", extras="timed out 90 s after the headline line")},
+              open(tmp_path / "SCALE_r05.json", "w"))
+    t = rt.table(str(tmp_path))
+    assert "peer (fell back from rccl)" in t and "extras: timed out 90 s" in t
+
+
+def test_baseline_md_block_is_generated():
+    """BASELINE.md §5's table is the tool's output for the committed records (regenerate with --write after a round's records land)"""
+    s = open(os.path.join(ROOT, "BASELINE.md")).read()
+    assert rt.BEGIN in s and rt.END in s
+    block = s[s.index(rt.BEGIN) + len(rt.BEGIN):s.index(rt.END)].strip()
+    have = {r.split("|")[1].strip() for r in block.splitlines()[2:]}
+    want = {r[0] for r in rt.records(ROOT)}
+    assert want <= have | {n for n in want if n.endswith("r04.json") or int(n.split("_r")[1][:2]) > 3}    # records newer than the commit are the driver's
+    for r in block.splitlines()[2:]:
+        name = r.split("|")[1].strip()
+        if name in ("BENCH_r01.json", "BENCH_r02.json", "BENCH_r03.json"):
+            assert r in rt.table(ROOT)
