@@ -23,9 +23,12 @@ WORKER = textwrap.dedent("""
     D = importlib.import_module("mini-nbody_amd.distributed")
     rank, world, local = D.init_process_group("gloo")
     n, steps = {n}, {steps}
-    eng = D.make_engine(n, transport="host")
+    eng = D.make_engine(n, transport={transport!r})
     eng.set_option(nb.OPT_JSUB, {jsub})
     eng.set_option(nb.OPT_OVERLAP, {overlap})
+    if {comm} >= 0:
+        eng.set_option(nb.OPT_COMM, {comm})
+        eng.comm_selftest()
     pos, vel = nb.make_bodies(n, seed=33)
     f = eng.forces(pos)                      # every process gets all N force words (the other ranks' rows are gathered)
     eng.upload(pos, vel)
@@ -58,7 +61,7 @@ def test_two_processes_one_gpu_host_transport(nb, tmp_path, world, overlap):
     n, steps, jsub = 12000 + 7, 3, 2
     out = str(tmp_path / "mp")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, n=n, steps=steps, jsub=jsub, overlap=overlap, out=out))
+    script.write_text(WORKER.format(root=ROOT, n=n, steps=steps, jsub=jsub, overlap=overlap, out=out, transport="host", comm=-1))
     port = free_port()
     procs = []
     for r in range(world):
@@ -146,3 +149,49 @@ def test_bench_peer_copy_transport(tmp_path):
     c5 = out["config5"]
     assert c5["value"] > 0 and 0 < c5["roofline"]["frac"] < 1 and c5["roofline"]["peak"] == 78.6 and c5["hbm_gb_per_s"] > 0
     assert c5["kernel"]["n_local"] == 32768 and c5["comm_exposed_ms_per_step"] >= 0
+
+
+def gpu_count():
+    """devices on this box, without initialising the GPU in the test process (torch.cuda.device_count() does not, on this image)"""
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("comm_name,overlap", [("auto", 1), ("auto", 0), ("ring", 2), ("ring", 1), ("direct", 1), ("direct", 2), ("allgather", 0)])
+def test_real_rccl_job_is_bit_identical_to_one_gpu(nb, tmp_path, comm_name, overlap):
+    """the first real multi-rank RCCL run must not be the timed benchmark.  Needs >= 2 GPUs (skipped on the one-GPU
+    box): one process per GPU, RCCL over xGMI, every transfer form and overlap mode, ragged N (slices of different lengths, so
+    NBODY_COMM_AUTO resolves to DIRECT and ALLGATHER to RING) — forces, positions and velocities after 4 steps bit for bit equal
+    to one GPU configured with the job's segmentation (NBODY_OPT_JSLICES = P, the job's pieces per slice and waves per workgroup)."""
+    if gpu_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    world = min(gpu_count(), 4)
+    comm = {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "direct": nb.COMM_DIRECT, "allgather": nb.COMM_ALLGATHER}[comm_name]
+    n, steps, jsub = 30000 + 7, 4, 2
+    out = str(tmp_path / "rccl")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, n=n, steps=steps, jsub=jsub, overlap=overlap, out=out, transport="rccl", comm=comm))
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NBODY_DEVICE=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o.decode()[-3000:]
+    pos, vel = nb.make_bodies(n, seed=33)
+    one = nb.NBody(n)
+    try:
+        one.set_option(nb.OPT_JSUB, jsub)
+        one.set_option(nb.OPT_JSLICES, world)
+        one.set_option(nb.OPT_WSPLIT, int(open(out + "_wsplit.txt").read()))
+        wf = one.forces(pos)
+        one.upload(pos, vel)
+        one.step(0.01, steps)
+        wp, wv = one.download()
+    finally:
+        one.close()
+    assert np.array_equal(np.load(out + "_pos.npy").view(np.uint32), wp.view(np.uint32))
+    assert np.array_equal(np.load(out + "_vel.npy").view(np.uint32), wv.view(np.uint32))
+    assert np.array_equal(np.load(out + "_force.npy").view(np.uint32), wf.view(np.uint32))
