@@ -31,7 +31,7 @@ build/nbody: $(PKG)/host/nbody.c include/nbody.h include/nbody_ic.h $(PKG)/libnb
 oracle:
 	$(MAKE) -C oracle
 
-microbench: build/microbench build/microbench_streams build/microbench_roles build/microbench_mfma
+microbench: build/microbench build/microbench_streams build/microbench_roles build/microbench_mfma build/microbench_gridsync
 build/microbench: $(CSRC)/microbench.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
@@ -51,6 +51,11 @@ $(CSRC)/force_loop_mfma_gfx950.inc: tools/gen_mfma_loop.py
 build/microbench_mfma: $(CSRC)/microbench_mfma.hip $(CSRC)/force_loop_mfma_gfx950.inc
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -o $@ $<
+
+# round 4: what a step boundary costs inside a launch against the kernel boundary (profiles/r04_step_boundary.md)
+build/microbench_gridsync: $(CSRC)/microbench_gridsync.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 
 # generated sources: the hand-scheduled loop (committed) and the microbenchmark streams (not tracked)
 gen:

@@ -78,6 +78,37 @@ __global__ void __launch_bounds__(256) step_kernel(u4* buf0, u4* buf1, unsigned 
   if (bad) atomicAdd(errors, bad);
 }
 
+// the same with the arrivals sharded: workgroup w adds to shard w mod SHARDS (256 B apart); the workgroup whose add completes a
+// shard's count for the step adds to the top counter, which everybody polls — same-address atomics serialise at the memory side
+// (~25 ns each), so a single counter costs workgroups x 25 ns per step and the tree SHARDS x 25 ns + workgroups / SHARDS x 25 ns
+constexpr int SHARDS = 64;
+__global__ void __launch_bounds__(256) persist_tree_kernel(u4* buf0, u4* buf1, unsigned* counter, int steps, int* errors, int* timeouts) {
+  const int nwg = gridDim.x;
+  const int shard = blockIdx.x % SHARDS;
+  const unsigned in_shard = (unsigned)((nwg - shard + SHARDS - 1) / SHARDS);
+  const unsigned nshards = (unsigned)(nwg < SHARDS ? nwg : SHARDS);
+  unsigned* top = counter + SHARDS * 64;
+  int bad = 0;
+  for (int s = 0; s < steps; ++s) {
+    u4* dst = (s & 1) ? buf1 : buf0;
+    write_rows(dst, blockIdx.x, (unsigned)s);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned t = __hip_atomic_fetch_add(counter + shard * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == in_shard * (unsigned)(s + 1) - 1u) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = nshards * (unsigned)(s + 1);
+      int spins = 0;
+      while (poll_sc1(top) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) { atomicAdd(timeouts, 1); break; }
+      }
+    }
+    __syncthreads();
+    bad += check_rows<false>(dst, blockIdx.x, nwg, (unsigned)s);
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+
 template <int ACQUIRE>
 __global__ void __launch_bounds__(256) persist_kernel(u4* buf0, u4* buf1, unsigned* counter, int steps, int* errors, int* timeouts) {
   const int nwg = gridDim.x;
@@ -117,7 +148,7 @@ int main(int argc, char** argv) {
   int *errors, *timeouts;
   const int max_wg = cus * 8;
   CK(hipMalloc(&b0, (size_t)max_wg * 64 * 16)); CK(hipMalloc(&b1, (size_t)max_wg * 64 * 16));
-  CK(hipMalloc(&counter, 256)); CK(hipMalloc(&errors, 4)); CK(hipMalloc(&timeouts, 4));
+  CK(hipMalloc(&counter, (SHARDS + 1) * 256)); CK(hipMalloc(&errors, 4)); CK(hipMalloc(&timeouts, 4));
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0, e1;
@@ -154,11 +185,11 @@ int main(int argc, char** argv) {
       CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     // ---- one cooperative launch
-    for (int acq = 0; acq < 2; ++acq) {
-      CK(hipMemset(errors, 0, 4)); CK(hipMemset(timeouts, 0, 4)); CK(hipMemset(counter, 0, 256));
+    for (int acq = 0; acq < 3; ++acq) {
+      CK(hipMemset(errors, 0, 4)); CK(hipMemset(timeouts, 0, 4)); CK(hipMemset(counter, 0, (SHARDS + 1) * 256));
       int nsteps = steps;
       void* args[] = {&b0, &b1, &counter, &nsteps, &errors, &timeouts};
-      const void* fn = acq ? (const void*)persist_kernel<1> : (const void*)persist_kernel<0>;
+      const void* fn = acq == 2 ? (const void*)persist_tree_kernel : acq ? (const void*)persist_kernel<1> : (const void*)persist_kernel<0>;
       int occ = 0;
       CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0));
       if (nwg > occ * cus) { printf("persist: %d workgroups exceed the co-resident capacity %d: not launched\n", nwg, occ * cus); continue; }
@@ -168,7 +199,7 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e1, st));
       CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      report(acq ? "one launch, counter + agent acquire" : "one launch, counter, sc1 loads", nwg, ms);
+      report(acq == 2 ? "one launch, 64 shards + top counter" : acq ? "one launch, counter + agent acquire" : "one launch, counter, sc1 loads", nwg, ms);
     }
   }
   return 0;
