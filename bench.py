@@ -550,6 +550,8 @@ def main(argv=None):
                     help="N > 1: seconds after `import torch` returned within which the transport must be up and self-tested (a hang in the first collective)")
     ap.add_argument("--extras-deadline", type=float, default=90.0,
                     help="N > 1: seconds the extras pass may take after the headline line appeared; past it the headline is returned alone")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="N > 1, RCCL, --comm auto: keep the library's default transfer form instead of measuring the three forms in warm-up")
     ap.add_argument("--no-fallback", action="store_true",
                     help="N > 1: if the requested transport fails, exit with code 3 instead of retrying on peer copies / the host")
     ap.add_argument("--extras", choices=["auto", "off", "forms", "all"], default="auto",
@@ -712,6 +714,12 @@ def main(argv=None):
     if eng is not None:
         pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
         eng.upload(pos, vel)                      # inputs resident in HBM before the timed region
+    autotuned = None
+    if world > 1 and transport == "rccl" and args.comm == "auto" and args.overlap == 1 and not args.no_autotune:
+        # warm-up, untimed: the three transfer forms measured on THIS job's links, the fastest kept (ties: the library's default)
+        chosen, form_ms = D.autotune_comm(eng, dt)
+        args.overlap = {"ring": 2}.get(chosen, 1)
+        autotuned = "autotuned in warm-up (ms per step: %s) -> %s" % (", ".join("%s %.3f" % kv for kv in form_ms.items()), chosen)
 
     share = float(n) * float(n) / world
     inline = args.events == "inline" or (args.events == "auto" and share >= 1e10)
@@ -757,8 +765,9 @@ def main(argv=None):
                                    % (n, "fp64" if args.fp64 else "fp32", args.seed),
                        "n_bodies": n, "pairs_per_step": pairs_per_step, "parallelism": "bodies sharded over %d GPU(s)" % world,
                        "kernel": cfg, "kernel_source_sha": kernel_source_sha(),
-                       "comm": ("%s / %s / overlap %d / stream priority %d" % ("hipMemcpyPeerAsync" if peer else COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?"),
-                                                                        transport, args.overlap, eng.info(nb._lib.INFO_COMM_PRIORITY))) if world > 1 else None,
+                       "comm": ("%s / %s / overlap %d / stream priority %d%s" % ("hipMemcpyPeerAsync" if peer else COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?"),
+                                                                          transport, args.overlap, eng.info(nb._lib.INFO_COMM_PRIORITY),
+                                                                          " / " + autotuned if autotuned else "")) if world > 1 else None,
                        "graph_replay": bool(world == 1 and not inline and args.steps >= 4),
                        "finite": finite},
             "roofline": roof,
@@ -818,10 +827,7 @@ def comm_forms_pass(eng, nb, args, world, n, transport, run_timed, steps=3):
         if eng is not None and comm is not None:
             entry["form_resolved"] = COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?")     # allgather needs equal slices: ring otherwise
         res[name] = entry
-    if eng is not None and transport == "rccl":
-        eng.set_option(nb.OPT_COMM, {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "allgather": nb.COMM_ALLGATHER, "direct": nb.COMM_DIRECT}[args.comm])
-        eng.set_option(nb.OPT_OVERLAP, args.overlap)
-    return res
+    return res        # (the engine is closed right after this pass: its options are not restored)
 
 
 def config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_of, np, steps=2):

@@ -87,3 +87,51 @@ def make_engine(n, fp64=False, tile=0, transport="auto"):
     eng.set_host_gather(gloo_host_gather)
     eng.transport = "host-staged via torch.distributed" + (" (RCCL unavailable: %s)" % err if err else "")
     return eng
+
+
+# the transfer forms a multi-rank RCCL job can take for its per-step all-gather of positions, as (name, NBODY_OPT_COMM, NBODY_OPT_OVERLAP):
+# the library's default first (ties keep it)
+def comm_candidates(L):
+    return [("allgather", L.COMM_ALLGATHER, 1), ("direct", L.COMM_DIRECT, 1), ("ring", L.COMM_RING, 2)]
+
+
+def autotune_comm(eng, dt=0.01, steps=2, margin=0.01, candidates=None, set_option=None):
+    """Choose the transfer form by MEASUREMENT on the job's own hardware, during warm-up: every candidate runs one untimed and
+    `steps` timed steps on the live engine, the slowest rank's time counts (all-reduce MAX over the control plane), and the
+    fastest form is kept — the library's default unless another one is more than `margin` faster.  Every rank makes the same
+    choice from the same all-reduced numbers (the forms are different RCCL call sequences: a disagreement would deadlock).
+    The result of a step does not depend on the form, only its duration does.
+    Why: which form hides best behind the own-slice kernel was decided on ONE GPU with a one-rank communicator
+    (profiles/r03_comm_under_load.md); the first job on real xGMI links measures it instead of trusting that.
+    Returns (chosen name, {name: ms per step}); the engine is left configured with the choice."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import _lib as L
+    cands = candidates or comm_candidates(L)
+    if candidates is None and eng.n % max(1, env_rank()[1]) != 0:
+        # slices of different lengths: ncclAllGather does not apply (the library would run the ring for it); its default is DIRECT
+        cands = [c for c in cands if c[0] != "allgather"]
+    setopt = set_option or eng.set_option
+    ms = {}
+    for name, comm, overlap in cands:
+        setopt(L.OPT_COMM, comm)
+        setopt(L.OPT_OVERLAP, overlap)
+        eng.step(dt, 1)
+        eng.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        eng.step(dt, steps)
+        eng.sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms[name] = float(t[0]) * 1e3 / steps
+    best = cands[0][0]
+    for name, _, _ in cands[1:]:
+        if ms[name] < ms[best] * (1.0 - margin):
+            best = name
+    for name, comm, overlap in cands:
+        if name == best:
+            setopt(L.OPT_COMM, comm)
+            setopt(L.OPT_OVERLAP, overlap)
+    return best, ms
