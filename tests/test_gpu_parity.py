@@ -81,6 +81,46 @@ def set_variant(nb, eng, variant, iblock, jsub=0, jslices=1, arith=None, wsplit=
         eng.set_option(nb.OPT_ARITH, arith)
 
 
+def test_random_configurations_strict_bit_exact(nb, oracle_fast, engine_factory):
+    """A seeded walk through the configuration space — size (1 … 6000, ragged), delivery variant and bodies per lane, pieces per slice,
+    source slices, wave split, summation order and block length, combine form, XCD placement, d2 form — 48 draws: in strict arithmetic
+    forces, a window of rows and three steps of the device loop equal the oracle in the order the engine reports, bit for bit.  Whatever
+    combination the options resolve to (some are overridden: the wave split exists for one body per lane only), the engine's `order` must
+    describe what it did."""
+    rng = np.random.default_rng(20241004)
+    blocks = (64, 256, 1024, 4096)
+    for draw in range(48):
+        n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 1024, 1025, 2085, 4096, 5000, 6000])) if draw % 3 else int(rng.integers(1, 6001))
+        variant = str(rng.choice(["auto", "smem", "lds", "readlane"]))
+        iblock = int(rng.choice({"auto": [0], "smem": [1, 2, 4, 8], "lds": [1, 2, 4], "readlane": [1, 2, 4]}[variant]))
+        jsub, jsl = int(rng.choice([0, 1, 2, 3, 5, 8])), int(rng.choice([1, 1, 2, 3]))
+        if n < jsl:
+            jsl = 1
+        wsplit = int(rng.choice([-1, 1, 4, 16]))
+        summ = str(rng.choice(["blocked", "blocked", "seq"]))
+        block, fuse, xcd = int(rng.choice(blocks)), int(rng.choice([1, 0])), int(rng.choice([0, 1]))
+        arith, d2 = ((nb.ARITH_STRICT, O.D2_FMA3), (nb.ARITH_REFERENCE_STRICT, O.D2_REFERENCE))[int(rng.integers(0, 2))]
+        pos, vel = nb.make_bodies(n, seed=1000 + draw)
+        eng = engine_factory(n)
+        set_variant(nb, eng, variant, iblock, jsub=jsub, jslices=jsl, arith=arith, wsplit=wsplit)
+        eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED if summ == "blocked" else nb.SUM_SEQ)
+        eng.set_option(nb.OPT_SUM_BLOCK, block)
+        eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+        eng.set_option(nb.OPT_XCD_MAP, xcd)
+        what = (draw, n, variant, iblock, jsub, jsl, wsplit, summ, block, fuse, xcd, arith, eng.config)
+        order = O.order(d2=d2, **eng.order)
+        f = eng.forces(pos)
+        assert np.array_equal(bits(f), bits(oracle_fast.forces_order(pos, order_=order))), what
+        r0, cnt = (n // 3, max(1, min(200, n - n // 3)))
+        eng.upload(pos, vel)
+        assert np.array_equal(bits(eng.forces_rows(r0, cnt)), bits(f[r0:r0 + cnt])), what
+        eng.step(0.01, 3)
+        gp, gv = eng.download()
+        op, ov = pos.copy(), vel.copy()
+        oracle_fast.step_order(op, ov, 0.01, 3, order_=order)
+        assert np.array_equal(bits(gp), bits(op)) and np.array_equal(bits(gv), bits(ov)), what
+
+
 def test_defaults_are_the_timed_configuration(nb, engine_factory):
     eng = engine_factory(1 << 16)
     cfg = eng.config
