@@ -6,7 +6,7 @@
  * with the first iteration excluded as warm-up, and the metric of BASELINE.md
  * §2: billion pair-interactions/s = N^2 * timed_steps / seconds / 1e9.
  *
- * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K]
+ * usage: nbody [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--rtl] [--jsub K]
  *              [--sum seq|blocked] [--block K] [--one-launch | --two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4|16]
  */
 #define _POSIX_C_SOURCE 199309L
@@ -27,7 +27,7 @@ static double now_s(void) {
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s failed: %s\n", #call, nbody_error_string(rc_)); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, npos = 0, jsub = 0, sum = -1, block = 0, two_launch = -1, long_buffers = -1, overlap = -1, wsplit = 0;
+  int n = 30000, iters = 10, gpus = 1, fp64 = 0, tile = 0, host_loop = 0, strict = 0, rtl = 0, npos = 0, jsub = 0, sum = -1, block = 0, two_launch = -1, long_buffers = -1, overlap = -1, wsplit = 0;
   unsigned long long seed = NBODY_IC_DEFAULT_SEED;
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
@@ -37,6 +37,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--fp64")) fp64 = 1;
     else if (!strcmp(argv[a], "--host-loop")) host_loop = 1;
     else if (!strcmp(argv[a], "--strict")) strict = 1;
+    else if (!strcmp(argv[a], "--rtl")) rtl = 1;
     else if (!strcmp(argv[a], "--two-launch")) two_launch = 1;
     else if (!strcmp(argv[a], "--one-launch")) two_launch = 0;
     else if (!strcmp(argv[a], "--overlap") && a + 1 < argc) overlap = atoi(argv[++a]);
@@ -46,13 +47,21 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--block") && a + 1 < argc) block = atoi(argv[++a]);
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4|16]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--gpus P] [--fp64] [--tile T] [--host-loop] [--seed S] [--strict] [--rtl] [--jsub K] [--sum seq|blocked] [--block K] [--one-launch|--two-launch] [--long-buffers 0|1] [--overlap 0|1|2] [--wsplit 1|4|16]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   const float dt = 0.01f;
   const size_t words = (size_t)n * 4;
   CHECK(nbody_init(n, gpus, fp64, tile));
   if (strict) CHECK(nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_STRICT));   /* IEEE-exact: bit-identical to the CPU oracle */
+  if (rtl) {
+    /* the RTL-faithful result: the reference's own five roundings for d2 (S/dxy.vhd:113-122, S/dzsoft.vhd:201-202,
+       S/dxyz_soft.vhd:149-150), 1/sqrt rounded once, and its own summation — 16 interleaved partial sums per axis over ONE stream of all
+       N sources, latched rotated, joined by the adder tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104, S/top_level.vhd:233-254) */
+    CHECK(nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_REFERENCE_STRICT));
+    CHECK(nbody_set_option(NBODY_OPT_SUM_ORDER, NBODY_SUM_FPGA16));
+    CHECK(nbody_set_option(NBODY_OPT_JSUB, 1));
+  }
   if (jsub > 0) CHECK(nbody_set_option(NBODY_OPT_JSUB, jsub));                 /* source segments (summation order) */
   if (sum >= 0) CHECK(nbody_set_option(NBODY_OPT_SUM_ORDER, sum));             /* one sequential sum per segment, or blocks */
   if (block > 0) CHECK(nbody_set_option(NBODY_OPT_SUM_BLOCK, block));

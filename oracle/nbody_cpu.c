@@ -8,7 +8,7 @@
  * --sum blocked [--block K] [--segments S] [--wsplit W]: the GPU engine's order (blocks of K sources, S source segments
  * of W pieces each).
  *
- * usage: nbody_cpu [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T] [--sum seq|blocked] [--block K] [--segments S] [--wsplit W]
+ * usage: nbody_cpu [N] [iters] [--fp64] [--seed S] [--divsqrt] [--rtl] [--threads T] [--sum seq|blocked] [--block K] [--segments S] [--wsplit W]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -25,11 +25,12 @@ static double now_s(void) {
 }
 
 int main(int argc, char **argv) {
-  int n = 4096, iters = 10, fp64 = 0, npos = 0, rsq = REF_RSQRT_F64, threads = 0, sum = REF_SUM_SEQ, block = 1024, segments = 1, wsplit = 1;
+  int n = 4096, iters = 10, fp64 = 0, npos = 0, rsq = REF_RSQRT_F64, rtl = 0, threads = 0, sum = REF_SUM_SEQ, block = 1024, segments = 1, wsplit = 1;
   unsigned long long seed = 42ull;
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--fp64")) fp64 = 1;
     else if (!strcmp(argv[a], "--divsqrt")) rsq = REF_RSQRT_DIVSQRT;
+    else if (!strcmp(argv[a], "--rtl")) rtl = 1;   /* the RTL's five roundings for d2 and its 16 partials + adder tree over one stream of all N sources */
     else if (!strcmp(argv[a], "--seed") && a + 1 < argc) seed = strtoull(argv[++a], NULL, 10);
     else if (!strcmp(argv[a], "--threads") && a + 1 < argc) threads = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--sum") && a + 1 < argc) { ++a; sum = !strcmp(argv[a], "blocked") ? REF_SUM_BLOCKED : REF_SUM_SEQ; }
@@ -38,7 +39,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--wsplit") && a + 1 < argc) wsplit = atoi(argv[++a]);
     else if (argv[a][0] != '-' && npos == 0) { n = atoi(argv[a]); npos++; }
     else if (argv[a][0] != '-' && npos == 1) { iters = atoi(argv[a]); npos++; }
-    else { fprintf(stderr, "usage: %s [N] [iters] [--fp64] [--seed S] [--divsqrt] [--threads T] [--sum seq|blocked] [--block K] [--segments S] [--wsplit W]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [N] [iters] [--fp64] [--seed S] [--divsqrt] [--rtl] [--threads T] [--sum seq|blocked] [--block K] [--segments S] [--wsplit W]\n", argv[0]); return 2; }
   }
   if (n <= 0 || iters < 2) { fprintf(stderr, "need N > 0 and iters >= 2 (iteration 1 is warm-up)\n"); return 2; }
   if (threads <= 0) {   /* small problems: do not wake more threads than there are 256-body chunks of rows */
@@ -54,7 +55,8 @@ int main(int argc, char **argv) {
     const ref_order_t order = {REF_D2_FMA3, rsq, sum, block, 1, segments > 0 ? segments : 1, wsplit > 0 ? wsplit : 1};
     for (int it = 1; it <= iters; ++it) {
       double t0 = now_s();
-      ref_step_f32_order(pos, vel, dt, n, 1, &order);   /* bodyForce (kick) + integrate (drift) */
+      if (rtl) ref_step_f32(pos, vel, dt, n, 1, REF_D2_REFERENCE, rsq, REF_SUM_FPGA16);
+      else ref_step_f32_order(pos, vel, dt, n, 1, &order);   /* bodyForce (kick) + integrate (drift) */
       if (it > 1) total += now_s() - t0;
     }
     for (int i = 0; i < n; ++i) { cx += pos[4 * i]; cy += pos[4 * i + 1]; cz += pos[4 * i + 2]; }

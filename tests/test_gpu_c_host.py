@@ -47,8 +47,10 @@ def test_gpu_host_program_and_cpu_program_print_the_same_checksum():
                                (["--sum", "blocked", "--segments", "16"], ["--jsub", "16", "--one-launch", "--wsplit", "1"]),
                                (["--sum", "blocked", "--segments", "8", "--wsplit", "4"], ["--jsub", "8", "--one-launch", "--wsplit", "4"]),
                                (["--sum", "blocked", "--segments", "4", "--wsplit", "16"], []),      # the engine's own choice at N = 4096
+                               (["--rtl"], ["--rtl"]),                                             # the RTL-faithful result
+                               (["--rtl"], ["--rtl", "--host-loop"]),
                                (["--sum", "blocked", "--block", "256", "--segments", "3", "--wsplit", "4"], ["--jsub", "3", "--block", "256", "--two-launch", "--wsplit", "4"])):
         a = subprocess.run([cpu, "4096", "10"] + cpu_args, capture_output=True, text=True, timeout=300)
-        b = subprocess.run([EXE, "4096", "10", "--strict"] + gpu_args, capture_output=True, text=True, timeout=300)
+        b = subprocess.run([EXE, "4096", "10"] + ([] if "--rtl" in gpu_args else ["--strict"]) + gpu_args, capture_output=True, text=True, timeout=300)
         assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
         assert line(a.stdout) == line(b.stdout), (cpu_args, gpu_args)

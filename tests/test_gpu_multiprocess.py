@@ -157,8 +157,7 @@ def gpu_count():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize("comm_name,overlap", [("auto", 1), ("auto", 0), ("ring", 2), ("ring", 1), ("direct", 1), ("direct", 2), ("allgather", 0)])
-def test_real_rccl_job_is_bit_identical_to_one_gpu(nb, tmp_path, comm_name, overlap):
+def test_real_rccl_job_is_bit_identical_to_one_gpu(nb, tmp_path):
     """the first real multi-rank RCCL run must not be the timed benchmark.  Needs >= 2 GPUs (skipped on the one-GPU
     box): one process per GPU, RCCL over xGMI, every transfer form and overlap mode, ragged N (slices of different lengths, so
     NBODY_COMM_AUTO resolves to DIRECT and ALLGATHER to RING) — forces, positions and velocities after 4 steps bit for bit equal
@@ -166,10 +165,15 @@ def test_real_rccl_job_is_bit_identical_to_one_gpu(nb, tmp_path, comm_name, over
     if gpu_count() < 2:
         pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
     world = min(gpu_count(), 4)
+    for comm_name, overlap in (("auto", 1), ("auto", 0), ("ring", 2), ("ring", 1), ("direct", 1), ("direct", 2), ("allgather", 0)):
+        _one_rccl_job(nb, tmp_path, world, comm_name, overlap)
+
+
+def _one_rccl_job(nb, tmp_path, world, comm_name, overlap):
     comm = {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "direct": nb.COMM_DIRECT, "allgather": nb.COMM_ALLGATHER}[comm_name]
     n, steps, jsub = 30000 + 7, 4, 2
-    out = str(tmp_path / "rccl")
-    script = tmp_path / "worker.py"
+    out = str(tmp_path / ("rccl_%s_%d" % (comm_name, overlap)))
+    script = tmp_path / ("worker_%s_%d.py" % (comm_name, overlap))
     script.write_text(WORKER.format(root=ROOT, n=n, steps=steps, jsub=jsub, overlap=overlap, out=out, transport="rccl", comm=comm))
     port = free_port()
     procs = []
@@ -179,7 +183,7 @@ def test_real_rccl_job_is_bit_identical_to_one_gpu(nb, tmp_path, comm_name, over
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         o, _ = p.communicate(timeout=600)
-        assert p.returncode == 0, o.decode()[-3000:]
+        assert p.returncode == 0, (comm_name, overlap, o.decode()[-3000:])
     pos, vel = nb.make_bodies(n, seed=33)
     one = nb.NBody(n)
     try:
@@ -192,9 +196,9 @@ def test_real_rccl_job_is_bit_identical_to_one_gpu(nb, tmp_path, comm_name, over
         wp, wv = one.download()
     finally:
         one.close()
-    assert np.array_equal(np.load(out + "_pos.npy").view(np.uint32), wp.view(np.uint32))
-    assert np.array_equal(np.load(out + "_vel.npy").view(np.uint32), wv.view(np.uint32))
-    assert np.array_equal(np.load(out + "_force.npy").view(np.uint32), wf.view(np.uint32))
+    assert np.array_equal(np.load(out + "_pos.npy").view(np.uint32), wp.view(np.uint32)), (comm_name, overlap)
+    assert np.array_equal(np.load(out + "_vel.npy").view(np.uint32), wv.view(np.uint32)), (comm_name, overlap)
+    assert np.array_equal(np.load(out + "_force.npy").view(np.uint32), wf.view(np.uint32)), (comm_name, overlap)
 
 
 def test_bench_under_torch_distributed_run(tmp_path):
