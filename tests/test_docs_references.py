@@ -1,0 +1,39 @@
+"""Every repository path the documents cite exists: DESIGN.md, BASELINE.md, README.md, INTEGRATION.md and profiles/README.md name
+their evidence by file (`profiles/...`, `tests/...`, `tools/...`, `mini-nbody_amd/...`, `oracle/...`, `include/...`); a stale name is
+a claim without its evidence."""
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOCS = ["DESIGN.md", "BASELINE.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")]
+PREFIXES = ("profiles/", "tests/", "tools/", "mini-nbody_amd/", "oracle/", "include/")
+BUILT = ("mini-nbody_amd/libnbody_hip.so", "mini-nbody_amd/libnbody_hip_diag.so", "oracle/libnbody_ref", "oracle/nbody_cpu", "oracle/_ref",
+         "mini-nbody_amd/csrc/microbench_streams.inc", "mini-nbody_amd/csrc/force_loop_mfma_gfx950.inc")     # made by `make`, git-ignored
+
+
+def cited_paths(text, doc):
+    out = set()
+    for tok in re.findall(r"`([^`\n]+)`", text):
+        tok = tok.strip()
+        if doc.startswith("profiles") and re.match(r"^(r0\d_|pmc_)[\w.*…{}-]+$", tok):
+            tok = "profiles/" + tok                    # profiles/README.md names its own files without the directory
+        if not tok.startswith(PREFIXES):
+            continue
+        tok = tok.split("::")[0].split(" ")[0].rstrip(".,;:)")
+        if "…" in tok or "<" in tok or "{" in tok or "$" in tok or tok.endswith("/"):
+            continue                                   # elided or templated names
+        out.add(tok)
+    return out
+
+
+def test_cited_paths_exist():
+    missing = []
+    for doc in DOCS:
+        text = open(os.path.join(ROOT, doc)).read()
+        for tok in sorted(cited_paths(text, doc)):
+            if tok.startswith(BUILT):
+                continue
+            if not glob.glob(os.path.join(ROOT, tok)):
+                missing.append((doc, tok))
+    assert not missing, missing
