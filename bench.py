@@ -30,8 +30,10 @@ processes, (a) three steps each of NBODY_COMM_RING with one launch per arriving 
 NBODY_COMM_ALLGATHER -> "comm_forms": {form: {ms_per_step, comm_exposed_ms_per_step, value}} (ring
 against direct over xGMI), and (b) at N = 8 BASELINE configs[4]: an fp64 N = 4,194,304 engine, 1 warm-up + 2 timed steps ->
 "config5": {value, ms_per_step, roofline, hbm_gb_per_s, comm_exposed_ms_per_step}; then a second line = headline + extras,
-which the supervisor prefers.  The extras have their own deadline (--extras-deadline, 90 s after the first line appeared):
-past it the workers are killed and the FIRST line is returned with "extras": "timed out ..." and exit code 0.
+after every finished extra rank 0 prints one more line = headline + extras so far, and the supervisor takes the LAST complete line.
+The extras have their own deadline (--extras-deadline, 90 s after the first line appeared): past it the workers are killed and that
+line is returned with "extras": "timed out ..." and exit code 0 — an extra that hangs costs neither the headline nor the extras
+finished before it.
 
 Rank 0 prints ONE JSON line, always with:
   roofline      the force kernel priced at 20 flop per pair against the fp32 (157.3 TFLOP/s) or
@@ -439,8 +441,9 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
             records.append(rec)
             if reason is None:
                 lines = json_lines(procs[0][1]) if lead else []
-                # an extras pass that ended badly leaves the headline: the FIRST line; otherwise the last (headline + extras)
-                obj = (lines[0] if info.get("extras") else lines[-1]) if lines else None
+                # every line rank 0 prints is the headline plus the extras finished so far: the LAST complete one is the fullest account,
+                # also when the extras pass ended badly (then "extras" says how)
+                obj = lines[-1] if lines else None
                 if lead and obj is None:
                     reason = "rank 0 printed no JSON line: " + tail(procs[0][2])
                     records[-1]["result"] = reason[:400]
@@ -550,8 +553,10 @@ def main(argv=None):
                     help="N > 1: seconds after `import torch` returned within which the transport must be up and self-tested (a hang in the first collective)")
     ap.add_argument("--extras-deadline", type=float, default=90.0,
                     help="N > 1: seconds the extras pass may take after the headline line appeared; past it the headline is returned alone")
-    ap.add_argument("--no-autotune", action="store_true",
-                    help="N > 1, RCCL, --comm auto: keep the library's default transfer form instead of measuring the three forms in warm-up")
+    ap.add_argument("--autotune", action="store_true",
+                    help="N > 1, RCCL, --comm auto: measure the three transfer forms in warm-up and time the fastest (off by default: the headline "
+                         "runs the library's default form — one ncclAllGather — and the other forms are measured by the extras pass, AFTER the "
+                         "headline line is out, so that a form that has never run on real links cannot cost the headline)")
     ap.add_argument("--no-fallback", action="store_true",
                     help="N > 1: if the requested transport fails, exit with code 3 instead of retrying on peer copies / the host")
     ap.add_argument("--extras", choices=["auto", "off", "forms", "all"], default="auto",
@@ -715,7 +720,7 @@ def main(argv=None):
         pos, vel = nb.make_bodies(n, seed=args.seed, dtype=np.float64 if args.fp64 else np.float32)
         eng.upload(pos, vel)                      # inputs resident in HBM before the timed region
     autotuned = None
-    if world > 1 and transport == "rccl" and args.comm == "auto" and args.overlap == 1 and not args.no_autotune:
+    if world > 1 and transport == "rccl" and args.comm == "auto" and args.overlap == 1 and args.autotune:
         # warm-up, untimed: the three transfer forms measured on THIS job's links, the fastest kept (ties: the library's default)
         chosen, form_ms = D.autotune_comm(eng, dt)
         args.overlap = {"ring": 2}.get(chosen, 1)
@@ -789,31 +794,31 @@ def main(argv=None):
         print(json.dumps(out), flush=True)            # THE HEADLINE LINE — out before any extra is attempted
     barrier()
     if extras:
-        ex = {}
+        def publish(key, value):
+            """rank 0: one more line = headline + the extras finished so far (the supervisor takes the last complete line, so a later
+            extra that hangs cannot take an earlier one with it)"""
+            if rank == 0:
+                out[key] = value
+                print(json.dumps(out), flush=True)
+
         if want_forms:
-            ex["comm_forms"] = comm_forms_pass(eng, nb, args, world, n, transport, run_timed)
+            comm_forms_pass(eng, nb, args, world, n, transport, run_timed, publish)
         if eng is not None:
             eng.close()
         if want_c5:
-            try:
-                ex["config5"] = config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_of, np)
-            except Exception as e:      # (a rank that fails here leaves the others in a collective: the supervisor's extras deadline ends that)
-                ex["config5"] = {"error": repr(e)}
-                raise
-        if rank == 0:
-            out.update(ex)
-            print(json.dumps(out), flush=True)        # headline + extras: the line the supervisor prefers
+            publish("config5", config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_of, np))
         barrier()
     if world > 1:
         dist.destroy_process_group()
 
 
-def comm_forms_pass(eng, nb, args, world, n, transport, run_timed, steps=3):
+def comm_forms_pass(eng, nb, args, world, n, transport, run_timed, publish, steps=3):
     """SURVEY.md §8(f) rank 4 measured where it can be: three steps each of the north_star's ring (P-1 dependent groups, one
     force launch per arriving slice), the DIRECT group (one hop over all links) and ncclAllGather, same engine, same state.
     Transports without forms (peer copies, host-staged) give one entry.  Every rank takes part (eng None: collectives only)."""
     if transport == "rccl":
-        forms = [("ring", nb.COMM_RING, 2), ("direct", nb.COMM_DIRECT, 1), ("allgather", nb.COMM_ALLGATHER, 1)]
+        # in ascending order of novelty: the all-gather is what the headline just ran; the ring's P-1 dependent groups come last
+        forms = [("allgather", nb.COMM_ALLGATHER, 1), ("direct", nb.COMM_DIRECT, 1), ("ring", nb.COMM_RING, 2)]
     else:
         forms = [("peer" if transport.startswith("peer") else "host", None, args.overlap)]
     res = {}
@@ -827,6 +832,7 @@ def comm_forms_pass(eng, nb, args, world, n, transport, run_timed, steps=3):
         if eng is not None and comm is not None:
             entry["form_resolved"] = COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?")     # allgather needs equal slices: ring otherwise
         res[name] = entry
+        publish("comm_forms", dict(res))
     return res        # (the engine is closed right after this pass: its options are not restored)
 
 

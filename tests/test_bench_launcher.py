@@ -47,6 +47,13 @@ STUB = textwrap.dedent('''
         sys.exit(5)
     if mode == "extrascrash":
         time.sleep(3600)          # the others sit in the collective the crashed rank never joins
+    if mode == "extraspartial":
+        if rank == 0:
+            line["comm_forms"] = {"allgather": {"ms_per_step": 30.5}}
+            print(json.dumps(line), flush=True)
+            sys.stdout.write('{"metric": "stub", "n_gpus": 3, "comm_forms": {"allgather": {"ms_pe')      # a line cut off mid-write
+            sys.stdout.flush()
+        time.sleep(3600)          # the second form hangs
     if mode == "extras" and rank == 0:
         time.sleep(0.3)
         line["comm_forms"] = {"ring": {"ms_per_step": 31.0}, "direct": {"ms_per_step": 30.0}, "allgather": {"ms_per_step": 30.5}}
@@ -273,3 +280,10 @@ def test_budget_spent_before_a_fallback_starts():
     code, obj = bench.supervise([sys.executable, "-c", "import time; time.sleep(3600)"], 2, [0, 1], "auto", deadline_s=600, budget_s=21.5,
                                 warm_import_s=0.0, reserve_s=9.5, min_attempt_s=0.5, t_start=time.time())
     assert code == 1 and obj is None      # attempt 0: 21.5 - 2 x 9.5 = 2.5 s; then < 20 s are left: peer and host are not started
+
+
+def test_an_extra_that_hangs_keeps_the_extras_finished_before_it(stub):
+    """rank 0 prints one more line after every finished extra; the supervisor takes the last COMPLETE line"""
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=600, extras_s=1.5, extra_env={"STUB_MODE": "extraspartial"})
+    assert code == 0 and obj["metric"] == "stub" and "argv" in obj
+    assert obj["comm_forms"] == {"allgather": {"ms_per_step": 30.5}} and obj["extras"].startswith("timed out")

@@ -87,9 +87,10 @@ def test_random_configurations_strict_bit_exact(nb, oracle_fast, engine_factory)
     forces, a window of rows and three steps of the device loop equal the oracle in the order the engine reports, bit for bit.  Whatever
     combination the options resolve to (some are overridden: the wave split exists for one body per lane only), the engine's `order` must
     describe what it did."""
-    rng = np.random.default_rng(20241004)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("NBODY_TEST_SEED", "20241004")))
     blocks = (64, 256, 1024, 4096)
-    for draw in range(48):
+    for draw in range(int(os.environ.get("NBODY_TEST_DRAWS", "48"))):      # (a soak run sets these: profiles/r04_random_configurations.txt)
         n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 1024, 1025, 2085, 4096, 5000, 6000])) if draw % 3 else int(rng.integers(1, 6001))
         variant = str(rng.choice(["auto", "smem", "lds", "readlane"]))
         iblock = int(rng.choice({"auto": [0], "smem": [1, 2, 4, 8], "lds": [1, 2, 4], "readlane": [1, 2, 4]}[variant]))
