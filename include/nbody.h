@@ -98,7 +98,9 @@ enum { NBODY_VARIANT_AUTO = 0,     /* ISA for the timed arithmetic (fp32, FMA3, 
 enum { NBODY_ARITH_FMA3 = 0,       /* d2 = fma(dx,dx,fma(dy,dy,fma(dz,dz,eps))): 11 VALU + v_rsq_f32 per pair.  THE TIMED MODE */
        NBODY_ARITH_REFERENCE = 1,  /* d2 = (dx*dx+dy*dy)+fma(dz,dz,eps): the RTL's rounding points, S/dxy.vhd:113-122, S/dzsoft.vhd:201-202, S/dxyz_soft.vhd:149-150 */
        NBODY_ARITH_STRICT = 2,     /* FMA3 with 1/sqrt rounded once from an fp64 evaluation instead of v_rsq_f32 (1 ulp):
-                                      every operation is then IEEE-exact and the result is bit-identical to the CPU oracle */
+                                      every operation is then IEEE-exact and the result is bit-identical to the CPU oracle.
+                                      In an fp64 context: 1/sqrt as IEEE sqrt and divide instead of v_rsq_f64 + one third-order
+                                      step — bit-identical to the oracle's fp64 evaluation in the configured summation order */
        NBODY_ARITH_REFERENCE_STRICT = 3 /* REFERENCE roundings + strict 1/sqrt */ };
 enum { NBODY_SUM_SEQ = 0,          /* one accumulator per segment, sources ascending (S/top_level.vhd:233-254) */
        NBODY_SUM_FPGA16 = 1,       /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */

@@ -163,6 +163,8 @@ void resolve_config() {
   // AUTO: the hand-scheduled ISA loop (+6 % over hipcc's schedule of the same operations, profiles/r01_sweep_isa.txt)
   g.variant = g.opt.variant == NBODY_VARIANT_AUTO ? NBODY_VARIANT_ISA : g.opt.variant;
   if (g.fp64 && g.variant != NBODY_VARIANT_ISA) g.variant = NBODY_VARIANT_SMEM;   // fp64: ISA loop or the compiled SMEM kernel
+  // fp64 strict arithmetic (IEEE sqrt and divide: bit-identical to the oracle) exists in the compiled kernel only
+  if (g.fp64 && (g.opt.arith & 2)) g.variant = NBODY_VARIANT_SMEM;
   // the hand-scheduled loops exist for the timed arithmetic only; the study modes use the C++ kernels
   if (g.variant == NBODY_VARIANT_ISA && (g.opt.arith != NBODY_ARITH_FMA3 || g.opt.sum_order == NBODY_SUM_FPGA16)) g.variant = NBODY_VARIANT_SMEM;
   int R = g.opt.iblock;
@@ -477,6 +479,15 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   if (g.fp64 && g.variant == NBODY_VARIANT_ISA) {
     if (g.opt.isa_phase == 2) return launch_isa_f64<2>(L, grid, a);
     return g.opt.isa_phase == 0 ? launch_isa_f64<0>(L, grid, a) : launch_isa_f64<1>(L, grid, a);
+  }
+  if (g.fp64 && (g.opt.arith & 2)) {   // NBODY_ARITH_STRICT / _REFERENCE_STRICT: IEEE 1/sqrt (fp64 has one d2 form: the bit-0 distinction is fp32's)
+    switch (R) {
+      case 1:
+        if (a.wsplit == 16) return launch_timed(L, force_smem_f64<1, 16, 1>, grid, a);
+        return a.wsplit == 4 ? launch_timed(L, force_smem_f64<1, 4, 1>, grid, a) : launch_timed(L, force_smem_f64<1, 1, 1>, grid, a);
+      case 2: return launch_timed(L, force_smem_f64<2, 1, 1>, grid, a);
+      default: return launch_timed(L, force_smem_f64<4, 1, 1>, grid, a);
+    }
   }
   if (g.fp64) {
     switch (R) {

@@ -175,11 +175,17 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
   y = __builtin_fma(y, q, y);
   return y;
 }
+// STRICT (NBODY_ARITH_STRICT in an fp64 context): 1/sqrt as IEEE square root and divide, both correctly rounded — the expression
+// oracle/nbody_ref.c evaluates — so that an fp64 run matches the oracle BIT FOR BIT in whatever summation order is configured
+// (the fp32 strict mode relies on the same two operations).  About 5x the cost of the seeded form; a parity mode, not the timed one.
+template <int STRICT = 0>
 __device__ __forceinline__ void pair_f64(double xj, double yj, double zj, double xi, double yi, double zi, double eps,
                                          double& ax, double& ay, double& az) {
   double dx = xj - xi, dy = yj - yi, dz = zj - zi;
   double d2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, __builtin_fma(dz, dz, eps)));
-  double inv = rsqrt_f64(d2);
+  double inv;
+  if constexpr (STRICT) inv = 1.0 / __builtin_sqrt(d2);
+  else inv = rsqrt_f64(d2);
   double inv2 = inv * inv;
   double inv3 = inv * inv2;
   ax = __builtin_fma(dx, inv3, ax);
@@ -862,7 +868,7 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
 // ---------------------------------------------------------------------------
 // fp64 (BASELINE config 5).  SMEM delivery, R bodies per lane.  One sequential sum per segment (fp64 has 29 more
 // bits than the 1e-5 target needs; sum_block is ignored).
-template <int R, int WS>
+template <int R, int WS, int STRICT = 0>
 __global__ void __launch_bounds__(wg_threads(WS)) force_smem_f64(ForceArgs a) {
   NB_WS_LDS(d4, WS);
   int seg, jb, je, lane_row;
@@ -883,13 +889,13 @@ __global__ void __launch_bounds__(wg_threads(WS)) force_smem_f64(ForceArgs a) {
 #pragma unroll
     for (int k = 0; k < G; ++k) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) pair_f64(cur[k].x, cur[k].y, cur[k].z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
+      for (int r = 0; r < R; ++r) pair_f64<STRICT>(cur[k].x, cur[k].y, cur[k].z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
     }
   }
   for (; j < je; ++j) {
     d4 p = src[j];
 #pragma unroll
-    for (int r = 0; r < R; ++r) pair_f64(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
+    for (int r = 0; r < R; ++r) pair_f64<STRICT>(p.x, p.y, p.z, me[r].x, me[r].y, me[r].z, eps, s.ax[r], s.ay[r], s.az[r]);
   }
   s.close(false, false);
   finish_rows<double, d4, R, WS>(seg, lane_row, row_end, me, s, ws_sums);

@@ -65,10 +65,11 @@ int main(int argc, char **argv) {
   } else {
     double *pos = (double *)malloc(sizeof(double) * 4 * (size_t)n), *vel = (double *)malloc(sizeof(double) * 4 * (size_t)n);
     ref_ic_f64(pos, vel, n, 0, n, seed);
+    /* the engine's fp64 order: segments x pieces of the wave split, one sequential sum per piece (1 x 1: the plain sequential sum) */
+    const ref_order_t order64 = {REF_D2_FMA3, REF_RSQRT_F64, REF_SUM_SEQ, block, 1, segments > 0 ? segments : 1, wsplit > 0 ? wsplit : 1};
     for (int it = 1; it <= iters; ++it) {
       double t0 = now_s();
-      ref_bodyForce_f64(pos, vel, (double)dt, n);
-      ref_integrate_f64(pos, vel, (double)dt, n);
+      ref_step_f64_order(pos, vel, (double)dt, n, 1, &order64);
       if (it > 1) total += now_s() - t0;
     }
     for (int i = 0; i < n; ++i) { cx += pos[4 * i]; cy += pos[4 * i + 1]; cz += pos[4 * i + 2]; }

@@ -353,6 +353,58 @@ void ref_forces_f32_order(const float *rows, int n_rows, const float *src, int n
 DEFINE_F64_KERNEL(ref_forces_f64, double)
 DEFINE_F64_KERNEL(ref_forces_f64_from_f32, float)
 
+/* fp64 in the engine's summation order (NBODY_ARITH_STRICT in an fp64 context matches this bit for bit): per row, for every segment
+ * in ascending order { for every piece of the wave split in ascending order: ONE sequential sum from +0 (fp64 contexts do not block);
+ * the segment's sum = ((p_0 + p_1) + p_2) + ... } then F = g_0, F = F + g_s — ref_order_t's nslices, sub and wsplit; block and the
+ * d2 / rsqrt modes do not apply (one d2 form, IEEE 1.0 / sqrt). */
+void ref_forces_f64_order(const double *rows, int n_rows, const double *src, int n_src, double *acc, const ref_order_t *o) {
+  if (n_rows <= 0) return;
+  const double soft = (double)bits_to_float(REF_SOFT_BITS);
+  const int nslices = o->nslices > 0 ? o->nslices : 1, sub = o->sub > 0 ? o->sub : 1, wsplit = o->wsplit > 0 ? o->wsplit : 1;
+  const int nblk = (n_rows + LANES - 1) / LANES;
+  _Pragma("omp parallel for schedule(dynamic, 4)")
+  for (int b = 0; b < nblk; ++b) {
+    double xs[LANES], ys[LANES], zs[LANES], tx[LANES], ty[LANES], tz[LANES];
+    for (int l = 0; l < LANES; ++l) {
+      int i = b * LANES + l; if (i >= n_rows) i = n_rows - 1;
+      xs[l] = rows[4 * i]; ys[l] = rows[4 * i + 1]; zs[l] = rows[4 * i + 2];
+      tx[l] = ty[l] = tz[l] = 0.0;
+    }
+    for (int seg = 0; seg < nslices * sub; ++seg) {
+      int sb, se;
+      ref_segment_bounds(seg / sub, seg % sub, n_src, nslices, sub, &sb, &se);
+      double gx[LANES], gy[LANES], gz[LANES];
+      for (int l = 0; l < LANES; ++l) gx[l] = gy[l] = gz[l] = 0.0;
+      for (int w = 0; w < wsplit; ++w) {
+        int jb, je;
+        ref_piece_bounds(sb, se, w, wsplit, &jb, &je);
+        double fx[LANES], fy[LANES], fz[LANES];
+        for (int l = 0; l < LANES; ++l) fx[l] = fy[l] = fz[l] = 0.0;
+        for (int j = jb; j < je; ++j) {
+          const double xt = src[4 * j], yt = src[4 * j + 1], zt = src[4 * j + 2];
+          _Pragma("omp simd")
+          for (int l = 0; l < LANES; ++l) {
+            double dx = xt - xs[l], dy = yt - ys[l], dz = zt - zs[l];
+            double d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, soft)));
+            double inv = 1.0 / sqrt(d2);
+            double inv2 = inv * inv;
+            double inv3 = inv * inv2;
+            fx[l] = fma(dx, inv3, fx[l]); fy[l] = fma(dy, inv3, fy[l]); fz[l] = fma(dz, inv3, fz[l]);
+          }
+        }
+        if (w == 0) { for (int l = 0; l < LANES; ++l) { gx[l] = fx[l]; gy[l] = fy[l]; gz[l] = fz[l]; } }
+        else { for (int l = 0; l < LANES; ++l) { gx[l] = gx[l] + fx[l]; gy[l] = gy[l] + fy[l]; gz[l] = gz[l] + fz[l]; } }
+      }
+      if (seg == 0) { for (int l = 0; l < LANES; ++l) { tx[l] = gx[l]; ty[l] = gy[l]; tz[l] = gz[l]; } }
+      else { for (int l = 0; l < LANES; ++l) { tx[l] = tx[l] + gx[l]; ty[l] = ty[l] + gy[l]; tz[l] = tz[l] + gz[l]; } }
+    }
+    for (int l = 0; l < LANES; ++l) {
+      int i = b * LANES + l; if (i >= n_rows) break;
+      acc[4 * i] = tx[l]; acc[4 * i + 1] = ty[l]; acc[4 * i + 2] = tz[l]; acc[4 * i + 3] = 0.0;
+    }
+  }
+}
+
 /* bodyForce(): kick.  v += dt * F with one rounding per component.  No reference
  * source (SURVEY.md §8(c) last sentence of the "must follow" row). */
 void ref_bodyForce_f32(const float *pos, float *vel, float dt, int n, int d2_mode, int rsqrt_mode, int sum_mode) {
@@ -384,6 +436,17 @@ void ref_step_f32(float *pos, float *vel, float dt, int n, int nsteps, int d2_mo
     ref_integrate_f32(pos, vel, dt, n);
   }
 }
+void ref_step_f64_order(double *pos, double *vel, double dt, int n, int nsteps, const ref_order_t *order) {
+  double *acc = (double *)malloc(sizeof(double) * 4 * (size_t)(n > 0 ? n : 1));
+  for (int s = 0; s < nsteps; ++s) {
+    ref_forces_f64_order(pos, n, pos, n, acc, order);
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < 3; ++c) vel[4 * i + c] = fma(dt, acc[4 * i + c], vel[4 * i + c]);
+    ref_integrate_f64(pos, vel, dt, n);
+  }
+  free(acc);
+}
+
 void ref_step_f32_order(float *pos, float *vel, float dt, int n, int nsteps, const ref_order_t *order) {
   float *acc = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
   for (int s = 0; s < nsteps; ++s) {

@@ -109,6 +109,10 @@ void ref_integrate_f64(double *pos, const double *vel, double dt, int n);
 /* nsteps x { bodyForce; integrate } */
 void ref_step_f32(float *pos, float *vel, float dt, int n, int nsteps, int d2_mode, int rsqrt_mode, int sum_mode);
 void ref_step_f64(double *pos, double *vel, double dt, int n, int nsteps);
+/* fp64 in the engine's summation order (segments x pieces of the wave split, one sequential sum per piece): what an fp64 context in
+ * NBODY_ARITH_STRICT reproduces bit for bit */
+void ref_forces_f64_order(const double *rows, int n_rows, const double *src, int n_src, double *acc, const ref_order_t *order);
+void ref_step_f64_order(double *pos, double *vel, double dt, int n, int nsteps, const ref_order_t *order);
 /* the same loop with the forces summed in the engine's order */
 void ref_step_f32_order(float *pos, float *vel, float dt, int n, int nsteps, const ref_order_t *order);
 

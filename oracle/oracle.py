@@ -71,6 +71,8 @@ class Oracle:
         L.ref_step_f64.argtypes = [_f64p, _f64p, C.c_double, C.c_int, C.c_int]
         L.ref_forces_f32_order.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _f32p, C.POINTER(Order)]
         L.ref_step_f32_order.argtypes = [_f32p, _f32p, f, C.c_int, C.c_int, C.POINTER(Order)]
+        L.ref_forces_f64_order.argtypes = [_f64p, C.c_int, _f64p, C.c_int, _f64p, C.POINTER(Order)]
+        L.ref_step_f64_order.argtypes = [_f64p, _f64p, C.c_double, C.c_int, C.c_int, C.POINTER(Order)]
         L.ref_segment_bounds.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 2
         L.ref_ic_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_uint64]
         L.ref_ic_f64.argtypes = [_f64p, _f64p, C.c_int, C.c_int, C.c_int, C.c_uint64]
@@ -134,6 +136,19 @@ class Oracle:
     def step_order(self, pos, vel, dt, nsteps, order_=None, **kw):
         o = order_ if order_ is not None else order(**kw)
         self.lib.ref_step_f32_order(pos, vel, dt, len(pos), nsteps, C.byref(o))
+
+    def forces_f64_order(self, rows, src=None, order_=None, **kw):
+        """fp64 forces in the engine's order (segments x wave-split pieces, one sequential sum per piece): the strict fp64 mode's twin"""
+        rows = np.ascontiguousarray(rows, np.float64).reshape(-1, 4)
+        src = rows if src is None else np.ascontiguousarray(src, np.float64).reshape(-1, 4)
+        o = order_ if order_ is not None else order(**kw)
+        acc = np.zeros_like(rows)
+        self.lib.ref_forces_f64_order(rows, len(rows), src, len(src), acc, C.byref(o))
+        return acc
+
+    def step_f64_order(self, pos, vel, dt, nsteps, order_=None, **kw):
+        o = order_ if order_ is not None else order(**kw)
+        self.lib.ref_step_f64_order(pos, vel, dt, len(pos), nsteps, C.byref(o))
 
     def segment_bounds(self, q, t, n, nslices, sub):
         b, e = C.c_int(), C.c_int()

@@ -66,3 +66,24 @@ def test_engine_fp64_within_bound_in_every_segmentation(nb, capsys):
     with capsys.disabled():
         print("\n[fp64 fixture] worst row / median in ulp of the row's largest component: " +
               "; ".join("%s W=%d nseg=%d: %.1f / %.1f" % s for s in seen[:12]))
+
+
+@pytest.mark.gpu
+def test_engine_fp64_strict_equals_the_oracle_and_the_fixture_bounds_both(nb, oracle_fast):
+    """NBODY_ARITH_STRICT in fp64 (IEEE sqrt and divide): bit-identical to the oracle in the engine's order — and both, being the same
+    numbers, sit inside the fixture's bound"""
+    import oracle as O
+    fx, pos, f = load()
+    eng = nb.NBody(fx["n"], fp64=True)
+    try:
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        for wsplit, jsub in ((1, 1), (4, 1), (16, 1), (4, 3), (1, 5)):
+            eng.set_option(nb.OPT_WSPLIT, wsplit)
+            eng.set_option(nb.OPT_JSUB, jsub)
+            o = eng.order
+            got = eng.forces(pos)
+            want = oracle_fast.forces_f64_order(pos, order_=O.order(nslices=o["nslices"], sub=o["sub"], wsplit=o["wsplit"]))
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (wsplit, jsub)
+            assert row_ulps(got, f).max() <= BOUND_ULP
+    finally:
+        eng.close()

@@ -54,3 +54,18 @@ def test_gpu_host_program_and_cpu_program_print_the_same_checksum():
         b = subprocess.run([EXE, "4096", "10"] + ([] if "--rtl" in gpu_args else ["--strict"]) + gpu_args, capture_output=True, text=True, timeout=300)
         assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
         assert line(a.stdout) == line(b.stdout), (cpu_args, gpu_args)
+
+
+def test_fp64_host_program_and_cpu_program_print_the_same_checksum():
+    """Round 4: `build/nbody --fp64 --strict` (IEEE sqrt and divide on the GPU) prints the 17-digit checksum of `oracle/nbody_cpu --fp64`
+    run in the order the engine reports — device loop and host-pointer loop"""
+    cpu = os.path.join(ROOT, "oracle", "nbody_cpu")
+    line = lambda out: [l for l in out.splitlines() if l.startswith("checksum")][0]
+    for extra in ([], ["--host-loop"], ["--jsub", "3", "--wsplit", "1"]):
+        b = subprocess.run([EXE, "4096", "6", "--fp64", "--strict"] + extra, capture_output=True, text=True, timeout=300)
+        assert b.returncode == 0, b.stderr
+        cfg = re.search(r"(\d+) segments x (\d+) pieces", b.stdout)
+        assert cfg, b.stdout
+        a = subprocess.run([cpu, "4096", "6", "--fp64", "--segments", cfg.group(1), "--wsplit", cfg.group(2)], capture_output=True, text=True, timeout=300)
+        assert a.returncode == 0, a.stderr
+        assert line(a.stdout) == line(b.stdout), (extra, cfg.groups())

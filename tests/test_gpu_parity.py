@@ -799,6 +799,16 @@ def test_config5_workload_fp64(nb, oracle_fast, engine_factory):
         want = oracle_fast.forces_f64(pos[first:first + cnt], pos)
         assert row_rel(got, want).max() < 1e-11, first        # different summation orders in fp64: ~sqrt(N) * 2^-53
         assert np.all(got[:, 3] == 0)
+    # the same windows in strict arithmetic (round 4): bit-identical to the oracle in the engine's order — the segmentation of config 5's
+    # size (64 L2-resident segments x 4 pieces), pinned to the last bit at full size
+    order0 = eng.order
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    assert eng.order == order0 and eng.config["nseg"] == cfg["nseg"] and eng.config["variant"] == "smem"
+    order = O.order(nslices=order0["nslices"], sub=order0["sub"], wsplit=order0["wsplit"])
+    for first, cnt in shard_edge_rows(n, 8, 16)[:4] + [(n // 2 - 64, 128)]:
+        got = eng.forces_rows(first, cnt)
+        assert np.array_equal(bits(got), bits(oracle_fast.forces_f64_order(pos[first:first + cnt], pos, order_=order))), first
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
     eng.step(0.01, 1)
     p1, v1 = eng.download()
     assert np.isfinite(p1).all() and np.isfinite(v1).all() and np.all(p1[:, 3] == 1) and np.all(v1[:, 3] == 0)
@@ -908,6 +918,55 @@ def test_mailbox_front_end(nb, oracle_fast, engine_factory):
     assert np.all(ram_b[:, 3] == 0)
     with pytest.raises(nb.NBodyError):                    # BEGIN not set -> nothing to do
         nb.mailbox.run(eng, ram_a)
+
+
+def test_fp64_strict_bit_exact(nb, oracle_fast, engine_factory):
+    """Round 4: NBODY_ARITH_STRICT in an fp64 context — 1/sqrt as IEEE sqrt and divide — is bit-identical to the oracle's fp64
+    evaluation in the engine's summation order (segments x pieces of the wave split, one sequential sum per piece): forces, row
+    windows, the device loop and the host-pointer loop, ragged sizes, 1/2/4 bodies per lane, 1/4/16 waves, both combine forms.
+    fp64 parity was tolerance-only before: a summation-order slip of last-bit size is now visible."""
+    for n in (1, 2, 63, 65, 257, 1000, 4099):
+        pos, vel = nb.make_bodies(n, seed=n, dtype=np.float64)
+        pos[:, :3] += nb.make_bodies(n, seed=n + 1, dtype=np.float64)[0][:, :3] * 2.0 ** -25       # full-width significands
+        eng = engine_factory(n, fp64=True)
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        for iblock, wsplit, jsub, jsl, fuse in ((0, -1, 0, 1, -1), (1, 1, 1, 1, 1), (1, 4, 3, 1, 1), (1, 16, 2, 1, 0), (2, 1, 5, 1, 1), (4, 1, 2, 3, 0), (1, 4, 2, 3, 1)):
+            if n < jsl:
+                continue
+            eng.set_option(nb.OPT_IBLOCK, iblock)
+            eng.set_option(nb.OPT_WSPLIT, wsplit)
+            eng.set_option(nb.OPT_JSUB, jsub)
+            eng.set_option(nb.OPT_JSLICES, jsl)
+            eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+            cfg = eng.config
+            assert cfg["variant"] == "smem", cfg                  # the strict arithmetic lives in the compiled kernel
+            o = eng.order
+            order = O.order(nslices=o["nslices"], sub=o["sub"], wsplit=o["wsplit"])
+            what = (n, iblock, wsplit, jsub, jsl, fuse, cfg)
+            f = eng.forces(pos)
+            assert np.array_equal(bits(f), bits(oracle_fast.forces_f64_order(pos, order_=order))), what
+            r0, cnt = n // 3, max(1, min(100, n - n // 3))
+            eng.upload(pos, vel)
+            assert np.array_equal(bits(eng.forces_rows(r0, cnt)), bits(f[r0:r0 + cnt])), what
+            eng.step(0.01, 4)
+            gp, gv = eng.download()
+            op, ov = pos.copy(), vel.copy()
+            oracle_fast.step_f64_order(op, ov, 0.01, 4, order_=order)
+            assert np.array_equal(bits(gp), bits(op)) and np.array_equal(bits(gv), bits(ov)), what
+        # host-pointer bodyForce_d()/integrate_d()
+        p2, v2 = pos.copy(), vel.copy()
+        eng.bodyForce(p2, v2, 0.01)
+        eng.integrate(p2, v2, 0.01)
+        o = eng.order
+        op, ov = pos.copy(), vel.copy()
+        oracle_fast.step_f64_order(op, ov, 0.01, 1, order_=O.order(nslices=o["nslices"], sub=o["sub"], wsplit=o["wsplit"]))
+        assert np.array_equal(bits(p2), bits(op)) and np.array_equal(bits(v2), bits(ov))
+        # the timed fp64 arithmetic (v_rsq_f64 + one third-order step) differs from it by a few ulp of 1/sqrt per pair only
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
+        fast = eng.forces(pos)
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        strict = eng.forces(pos)
+        assert np.array_equal(bits(fast), bits(strict)) or maxnorm_rel(fast, strict) < 1e-14       # (n = 1: the self pair alone, exactly zero)
 
 
 def test_fp64_path(nb, oracle_fast, engine_factory):

@@ -103,3 +103,36 @@ def test_blocked_sum_is_what_meets_the_tolerance(nb, oracle_fast):
     assert worst(oracle_fast.forces_order(rows, pos, summ=O.SUM_BLOCKED, sub=8)) < 5e-6
     assert worst(oracle_fast.forces_order(rows, pos, summ=O.SUM_BLOCKED, nslices=8, sub=8)) < 5e-6
     assert worst(oracle_fast.forces_f32(rows, pos)) > 1e-5
+
+
+def emulate_f64(ora, pos, rows, nslices, sub, nb, wsplit):
+    """the fp64 order: one sequential sum per piece (the plain fp64 kernel over that piece), piece sums S = w0, S = S + w_k,
+    segment sums F = g0, F = F + g_s; an empty piece contributes +0"""
+    n = len(pos)
+    total = None
+    for q in range(nslices):
+        for t in range(sub):
+            sb, se = nb.sharding.segment_bounds(q, t, n, nslices, sub)
+            seg = None
+            for w in range(wsplit):
+                b, e = nb.sharding.piece_bounds(sb, se, w, wsplit)
+                pc = ora.forces_f64(rows, pos[b:e]) if e > b else np.zeros_like(rows)
+                seg = pc if seg is None else seg + pc
+            total = seg if total is None else total + seg
+    total[:, 3] = 0
+    return total
+
+
+@pytest.mark.parametrize("n,nslices,sub,wsplit", [(700, 1, 1, 1), (1500, 3, 2, 1), (1029, 8, 1, 4), (700, 1, 1, 16), (5, 2, 2, 4), (3, 1, 1, 16), (300, 1, 3, 4)])
+def test_fp64_order_equals_emulation(nb, oracle, oracle_fast, n, nslices, sub, wsplit):
+    """ref_forces_f64_order (round 4: what an fp64 context in NBODY_ARITH_STRICT reproduces bit for bit) against an emulation built
+    from the plain sequential fp64 kernel; with one segment and one piece it IS that kernel"""
+    pos, _ = nb.make_bodies(n, seed=n, dtype=np.float64)
+    pos[:, :3] += nb.make_bodies(n, seed=n + 1, dtype=np.float64)[0][:, :3] * 2.0 ** -25      # full-width significands
+    for ora in (oracle, oracle_fast):
+        got = ora.forces_f64_order(pos, nslices=nslices, sub=sub, wsplit=wsplit)
+        assert np.array_equal(got.view(np.uint64), emulate_f64(ora, pos, pos, nslices, sub, nb, wsplit).view(np.uint64))
+    assert np.array_equal(oracle.forces_f64_order(pos, nslices=nslices, sub=sub, wsplit=wsplit).view(np.uint64),
+                          oracle_fast.forces_f64_order(pos, nslices=nslices, sub=sub, wsplit=wsplit).view(np.uint64))
+    if nslices == sub == wsplit == 1:
+        assert np.array_equal(oracle.forces_f64_order(pos, nslices=1, sub=1, wsplit=1).view(np.uint64), oracle.forces_f64(pos).view(np.uint64))
