@@ -663,7 +663,7 @@ def main(argv=None):
             return e
         return D.make_engine(bodies, fp64=fp64, tile=args.tile, transport=args.transport)
 
-    def roofline_of(e, cfg, r, bodies, fp64, steps, inline):
+    def roofline_of(e, cfg, r, bodies, fp64, inline):
         """the force kernel priced at 20 flop per pair against the vector peak; duration from HIP events on the compute stream"""
         dtype = "f64" if fp64 else "f32"
         n_local = cfg["n_local"]
@@ -745,7 +745,7 @@ def main(argv=None):
                    "sum_order": cfg["sum_order"], "sum_block": cfg["sum_block"], "launches_per_step": cfg["launches_per_step"],
                    "wsplit": cfg["wsplit"], "isa_phase": cfg["isa_phase"], "long_buffers": cfg["long_buffers"], "xcd_map": cfg["xcd_map"],
                    "kernel_source_sha": kernel_source_sha()}
-        roof = roofline_of(eng, cfg, r, n, args.fp64, args.steps, inline)
+        roof = roofline_of(eng, cfg, r, n, args.fp64, inline)
         pj = matching_pmc(run_cfg)
         if pj:
             roof["traffic"] = pj.get("hbm_bytes_per_launch")
@@ -802,17 +802,17 @@ def main(argv=None):
                 print(json.dumps(out), flush=True)
 
         if want_forms:
-            comm_forms_pass(eng, nb, args, world, n, transport, run_timed, publish)
+            comm_forms_pass(eng, nb, args, n, transport, run_timed, publish)
         if eng is not None:
             eng.close()
         if want_c5:
-            publish("config5", config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_of, np))
+            publish("config5", config5_pass(nb, args, world, rank, open_engine, run_timed, roofline_of, np))
         barrier()
     if world > 1:
         dist.destroy_process_group()
 
 
-def comm_forms_pass(eng, nb, args, world, n, transport, run_timed, publish, steps=3):
+def comm_forms_pass(eng, nb, args, n, transport, run_timed, publish, steps=3):
     """SURVEY.md §8(f) rank 4 measured where it can be: three steps each of the north_star's ring (P-1 dependent groups, one
     force launch per arriving slice), the DIRECT group (one hop over all links) and ncclAllGather, same engine, same state.
     Transports without forms (peer copies, host-staged) give one entry.  Every rank takes part (eng None: collectives only)."""
@@ -836,7 +836,7 @@ def comm_forms_pass(eng, nb, args, world, n, transport, run_timed, publish, step
     return res        # (the engine is closed right after this pass: its options are not restored)
 
 
-def config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_of, np, steps=2):
+def config5_pass(nb, args, world, rank, open_engine, run_timed, roofline_of, np, steps=2):
     """BASELINE configs[4]: N = 4,194,304 fp64 sharded over the job's GPUs, 1 warm-up + 2 timed steps, in the engine's own
     configuration.  "HBM GB/s vs peak" (the config's own words) = the algorithmic bytes of a step — 128 B per owned body: its
     position and velocity read and written — over the step time; the path stays VALU-bound."""
@@ -851,7 +851,7 @@ def config5_pass(nb, args, world, rank, peer, open_engine, run_timed, roofline_o
         res = None
         if rank == 0:
             cfg = e5.config
-            roof = roofline_of(e5, cfg, r, n5, True, steps, True)
+            roof = roofline_of(e5, cfg, r, n5, True, True)
             ms = 1e3 * r["elapsed"] / steps
             bytes_per_step = cfg["n_local"] * 128.0
             res = {"workload": "N=%d fp64 over %d GPU(s), %d timed steps" % (n5, world, steps),

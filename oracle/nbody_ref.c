@@ -6,6 +6,13 @@
  * integrator and no CPU path; bodyForce()/integrate() follow the
  * north_star text and are this build's own definitions.
  *
+ * PINNING.  **Parity unpinned at the reference level**: the reference's testbenches assert no values (T/tb_dxy.vhd:907-918,
+ * T/tb_sqrt.vhd:562-573 check only "not X"), it holds no expected outputs, and it cannot be built here (VHDL-2008 + seven vendor IP
+ * cores that are not in the tree: there is no oracle/_ref).  What pins this restatement instead: the testbenches' own stimuli with
+ * analytically derived outputs (tests/golden/kat_*.json), a cycle model of the scatter logic that IS in the tree
+ * (tests/test_fpga_scatter_model.py), and independent exact-rational third statements of the whole pipeline
+ * (tests/golden/make_system.py -> system_*.json, rtl_*.json; make_fp64.py -> fp64_n64.json), all reproduced bit for bit (fp64: bounded).
+ *
  * Build flavours (oracle/Makefile):
  *   libnbody_ref.so       -O2 -ffp-contract=off            bit-reproducible parity oracle
  *   libnbody_ref_fast.so  -O3 -ffp-contract=off -fopenmp   same source, same results, timed as cpu_baseline
