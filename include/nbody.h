@@ -101,7 +101,8 @@ enum { NBODY_ARITH_FMA3 = 0,       /* d2 = fma(dx,dx,fma(dy,dy,fma(dz,dz,eps))):
                                       every operation is then IEEE-exact and the result is bit-identical to the CPU oracle.
                                       In an fp64 context: 1/sqrt as IEEE sqrt and divide instead of v_rsq_f64 + one third-order
                                       step — bit-identical to the oracle's fp64 evaluation in the configured summation order */
-       NBODY_ARITH_REFERENCE_STRICT = 3 /* REFERENCE roundings + strict 1/sqrt */ };
+       NBODY_ARITH_REFERENCE_STRICT = 3 /* REFERENCE roundings + strict 1/sqrt (fp64 contexts have ONE d2 form — the fma-contracted one,
+                                           as the oracle's fp64 evaluation — so there REFERENCE = FMA3 and REFERENCE_STRICT = STRICT) */ };
 enum { NBODY_SUM_SEQ = 0,          /* one accumulator per segment, sources ascending (S/top_level.vhd:233-254) */
        NBODY_SUM_FPGA16 = 1,       /* 16 interleaved partials + pairwise tree (S/fxyz.vhd:129-184, S/final_adder.vhd:88-104) */
        NBODY_SUM_BLOCKED = 2       /* fp32 DEFAULT, THE TIMED MODE: two levels — blocks of NBODY_OPT_SUM_BLOCK consecutive sources
