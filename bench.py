@@ -39,7 +39,7 @@ Rank 0 prints ONE JSON line, always with:
   roofline      the force kernel priced at 20 flop per pair against the fp32 (157.3 TFLOP/s) or
                 fp64 (78.6: measured v_fma_f64 issue rate, profiles/r01_microbench_valu_issue.txt) VECTOR peak — no contraction for the matrix cores — with the kernel's
                 duration measured live by HIP events on the library's compute stream; beside it the instruction-issue
-                bound (30 cycles per wave-pair in fp32, 80 in fp64) and cycles per wave-pair.  `traffic` and the
+                bound (30 cycles per wave-pair in fp32, 76 in fp64) and cycles per wave-pair.  `traffic` and the
                 other *_pmc fields come from the committed rocprofv3 passes of THIS configuration
                 (profiles/pmc_*.json, tools/profile.sh) and are attached only when that profile's recorded
                 configuration equals the run's; otherwise `traffic` is null.
@@ -71,9 +71,9 @@ FLOP_PER_PAIR = 20                # SURVEY.md §8(d) convention (literal count: 
 # fp64: the guide states NO fp64 vector figure; 78.6 is this repository's own measurement — v_fma_f64 issues at 4.0 cycles per wave64
 # on a SIMD (profiles/r01_microbench_valu_issue.txt: v_fma_f64 / v_mul_f64 W=4, W=8), i.e. 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
 PEAK_VECTOR_TFLOPS = {"f32": 157.3, "f64": 78.6}
-# cycles of VALU issue per wave64 pair: fp32 11 x 2 + 8 (v_rsq_f32); fp64 16 x 4 + 16 (v_rsq_f64)
+# cycles of VALU issue per wave64 pair: fp32 11 x 2 + 8 (v_rsq_f32); fp64 15 x 4 + 16 (v_rsq_f64; round 4: the inverse cube in six operations, was 16 x 4 + 16)
 # measured: profiles/r01_microbench_valu_issue.txt, DESIGN.md §3
-ISSUE_CYCLES_PER_WAVE_PAIR = {"f32": 30, "f64": 80}
+ISSUE_CYCLES_PER_WAVE_PAIR = {"f32": 30, "f64": 76}
 METRIC = "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofline"
 COMM_NAMES = {0: "ring", 1: "allgather", 2: "auto", 3: "direct"}
 
@@ -690,7 +690,7 @@ def main(argv=None):
                 "cycles_per_wave_pair_at_nominal_clock": round(avg_launch_s * clk * simds / wave_pairs_per_launch, 2) if wave_pairs_per_launch else None,
                 "kernel_events": "inline (inside the timed region)" if inline else "separate pass of %d steps after the timed region (the timed region ran without events%s)" % (r["kernel_steps"], ", HIP-graph replay" if world == 1 else ""),
                 "note": "VALU-issue-bound: per pair 11 full-rate + 1 quarter-rate instruction in fp32 (30 cycles per wave64), "
-                        "16 + 1 in fp64 (80); neither HBM nor MFMA bounds it (no contraction; HBM traffic is 64 B per body per step)"}
+                        "15 + 1 in fp64 (76); neither HBM nor MFMA bounds it (no contraction; HBM traffic is 64 B per body per step)"}
 
     eng = open_engine(n, args.fp64)
     if eng is not None:
@@ -756,10 +756,10 @@ def main(argv=None):
                            "hbm_frac_of_peak": round(pj.get("hbm_frac_of_8tbs", 0.0), 5),
                            "kernel_ms_avg_trace": pj.get("force_kernel_avg_ms_trace"),
                            # "VALU-busy" as the north_star means it: (sum over the VALU instructions a wave issues for one pair of
-                           # their issue cycles: 11 x 2 + 8 in fp32, 16 x 4 + 16 in fp64, profiles/r01_microbench_valu_issue.txt)
+                           # their issue cycles: 11 x 2 + 8 in fp32, 15 x 4 + 16 in fp64, profiles/r01_microbench_valu_issue.txt)
                            # / the SIMD cycles the kernel actually took per wave-pair (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / wave-pairs)
                            "valu_issue_busy": round(ISSUE_CYCLES_PER_WAVE_PAIR[dtype] / pj["cycles_per_wave_pair"], 4) if pj.get("cycles_per_wave_pair") else None,
-                           "valu_issue_busy_formula": "(11 x 2 + 8 | 16 x 4 + 16 issue cycles per wave-pair) / measured SIMD cycles per wave-pair",
+                           "valu_issue_busy_formula": "(11 x 2 + 8 | 15 x 4 + 16 issue cycles per wave-pair) / measured SIMD cycles per wave-pair",
                            "sq_active_inst_valu_over_busy_cycles": pj.get("sq_valu_busy")}
         out = {
             "metric": METRIC if (n == (1 << 20) and not args.fp64) else "billion pair-interactions/s at N=%d %s" % (n, "fp64" if args.fp64 else "fp32"),

@@ -161,19 +161,19 @@ __device__ __forceinline__ void pair_f32(float xj, float yj, float zj, float xi,
   az = __builtin_fmaf(dz, inv3, az);
 }
 
-// fp64: v_rsq_f64 seed (about 2^-24 relative) + ONE third-order step: with e = 1 - x*y*y,
-//   x^(-1/2) = y (1 - e)^(-1/2) = y (1 + e/2 + 3/8 e^2 + 5/16 e^3 + ...),   y <- y + y*e*(1/2 + 3/8 e)
-// leaves (5/16) e^3 < 2^-70: full binary64 in 5 operations (round 1: two Newton steps, 7 operations).  Same
-// expression tree as oracle/nbody_ref.c ref_forces_f64 apart from how 1/sqrt is obtained, and the same operations in
-// the same order as the hand-scheduled fp64 loop (tools/gen_force_loop.py body_f64).
-__device__ __forceinline__ double rsqrt_f64(double x) {
+// fp64: x^(-3/2) straight from the v_rsq_f64 seed y (about 2^-24 relative) by ONE third-order step on the cube: with e = 1 - x*y^2,
+//   x^(-3/2) = y^3 (1 - e)^(-3/2) = y^3 (1 + 3/2 e + 15/8 e^2 + 35/16 e^3 + ...),   inv3 = y^3 + y^3 * e * (3/2 + 15/8 e)
+// leaves (35/16) e^3 < 2^-70: full binary64 in SIX operations (round 1: two Newton steps on y, then the cube: nine; rounds 2-3: one
+// third-order step on y, then the cube: seven).  Same expression tree as oracle/nbody_ref.c ref_forces_f64 apart from how the inverse
+// cube is obtained, and the same operations in the same order as the hand-scheduled fp64 loop (tools/gen_force_loop.py body_f64).
+__device__ __forceinline__ double inv3_f64(double x) {
   double y = __builtin_amdgcn_rsq(x);
-  double r = x * y;
-  double e = __builtin_fma(-r, y, 1.0);
-  double p = __builtin_fma(e, 0.375, 0.5);
+  double y2 = y * y;
+  double e = __builtin_fma(-x, y2, 1.0);
+  double y3 = y2 * y;
+  double p = __builtin_fma(e, 1.875, 1.5);
   double q = e * p;
-  y = __builtin_fma(y, q, y);
-  return y;
+  return __builtin_fma(y3, q, y3);
 }
 // STRICT (NBODY_ARITH_STRICT in an fp64 context): 1/sqrt as IEEE square root and divide, both correctly rounded — the expression
 // oracle/nbody_ref.c evaluates — so that an fp64 run matches the oracle BIT FOR BIT in whatever summation order is configured
@@ -183,11 +183,14 @@ __device__ __forceinline__ void pair_f64(double xj, double yj, double zj, double
                                          double& ax, double& ay, double& az) {
   double dx = xj - xi, dy = yj - yi, dz = zj - zi;
   double d2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, __builtin_fma(dz, dz, eps)));
-  double inv;
-  if constexpr (STRICT) inv = 1.0 / __builtin_sqrt(d2);
-  else inv = rsqrt_f64(d2);
-  double inv2 = inv * inv;
-  double inv3 = inv * inv2;
+  double inv3;
+  if constexpr (STRICT) {
+    double inv = 1.0 / __builtin_sqrt(d2);
+    double inv2 = inv * inv;
+    inv3 = inv * inv2;
+  } else {
+    inv3 = inv3_f64(d2);
+  }
   ax = __builtin_fma(dx, inv3, ax);
   ay = __builtin_fma(dy, inv3, ay);
   az = __builtin_fma(dz, inv3, az);

@@ -340,7 +340,8 @@ def sp(r):
     return "s[%d:%d]" % (r, r + 1)
 
 
-D_EPSV, D_KV = 46, 48      # experiment (F64_V2): eps and 0.375 in VGPR pairs instead of SGPR pairs
+D_EPSV, D_KV, D_KV2 = 46, 48, 50      # v[48:49] = 3/2 always (an instruction reads at most ONE SGPR constant on gfx9: 15/8 takes that slot);
+                                      # experiment (F64_V2): eps and 15/8 in VGPR pairs too instead of SGPR pairs
 
 
 def body_f64(k, sbase, b, vconst=False):
@@ -360,19 +361,21 @@ def body_f64(k, sbase, b, vconst=False):
         "v_fma_f64 %s, %s, %s, %s" % (vp(D_AY), vp(py), vp(yp), vp(D_AY)),
         "v_fma_f64 %s, %s, %s, %s" % (vp(D_AZ), vp(pz), vp(yp), vp(D_AZ)),
     ]
-    # one third-order step from the v_rsq_f64 seed (rsqrt_f64 in nbody_kernels.hpp): e = 1 - x*y*y,
-    # y <- y + y*e*(1/2 + 3/8 e): the error goes from e0 to (5/16) e0^3, full binary64 from a 2^-24 seed in 5 operations
-    out += ["v_mul_f64 %s, %s, %s" % (vp(D_R), vp(D_T), vp(y)),
-            "v_fma_f64 %s, -%s, %s, 1.0" % (vp(D_E), vp(D_R), vp(y)),
-            "v_fma_f64 %s, %s, %s, 0.5" % (vp(D_HX), vp(D_E), vp(D_KV) if vconst else sp(D_K375)),
+    # inv3 = x^(-3/2) straight from the v_rsq_f64 seed y (about 2^-24 relative), one third-order step on the CUBE (inv3_f64 in
+    # nbody_kernels.hpp, round 4): with e = 1 - x*y^2,  x^(-3/2) = y^3 (1 - e)^(-3/2) = y^3 (1 + e (3/2 + 15/8 e) + (35/16) e^3 ...),
+    # the e^3 term is < 2^-70: full binary64 in SIX operations — y2 = y*y, e = fma(-x, y2, 1), y3 = y2*y, p = fma(e, 15/8, 3/2), q = e*p,
+    # inv3 = fma(y3, q, y3) — where refining y first and cubing it afterwards took seven (round 2/3: 17 instructions per pair, now 16)
+    out += ["v_mul_f64 %s, %s, %s" % (vp(D_U), vp(y), vp(y)),
+            "v_fma_f64 %s, -%s, %s, 1.0" % (vp(D_E), vp(D_T), vp(D_U)),
+            "v_mul_f64 %s, %s, %s" % (vp(y), vp(D_U), vp(y)),
+            "v_fma_f64 %s, %s, %s, %s" % (vp(D_HX), vp(D_E), vp(D_KV2) if vconst else sp(D_K1875), vp(D_KV)),
             "v_mul_f64 %s, %s, %s" % (vp(D_E), vp(D_E), vp(D_HX)),
             "v_fma_f64 %s, %s, %s, %s" % (vp(y), vp(y), vp(D_E), vp(y))]
-    out += ["v_mul_f64 %s, %s, %s" % (vp(D_U), vp(y), vp(y)), "v_mul_f64 %s, %s, %s" % (vp(y), vp(y), vp(D_U))]
     return out
 
 
 F64_PTR, F64_CNT, F64_STRIDE = 68, 70, 71    # the fp64 loop keeps its own scalars (it is VGPR-limited to 5 waves anyway)
-D_K375 = 72                                  # s[72:73] = 0.375 (VOP3 takes no literal on gfx9: the constant lives in an SGPR pair)
+D_K1875 = 72                                 # s[72:73] = 15/8 (VOP3 takes no literal on gfx9: the constant lives in an SGPR pair)
 
 
 def build_f64(pad, vconst=False):
@@ -384,11 +387,12 @@ def build_f64(pad, vconst=False):
         "s_mov_b64 s[%d:%d], %%[p]" % (F64_PTR, F64_PTR + 1),
         "s_mov_b32 s%d, %%[groups]" % F64_CNT,
         "s_movk_i32 s%d, 0x80" % F64_STRIDE,
-        "s_mov_b32 s%d, 0" % D_K375, "s_mov_b32 s%d, 0x3fd80000" % (D_K375 + 1),
+        "s_mov_b32 s%d, 0" % D_K1875, "s_mov_b32 s%d, 0x3ffe0000" % (D_K1875 + 1),      # 1.875
+        "v_mov_b32 v%d, 0" % D_KV, "v_mov_b32 v%d, 0x3ff80000" % (D_KV + 1),           # 1.5
         "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x0" % (A_BASE, A_BASE + 15, F64_PTR, F64_PTR + 1),
     ]
     if vconst:
-        ins += ["v_mov_b64 %s, %s" % (vp(D_EPSV), sp(D_EPS)), "v_mov_b64 %s, %s" % (vp(D_KV), sp(D_K375))]
+        ins += ["v_mov_b64 %s, %s" % (vp(D_EPSV), sp(D_EPS)), "v_mov_b64 %s, %s" % (vp(D_KV2), sp(D_K1875))]
     ins += ["v_mov_b64 %s, 0" % vp(r) for r in (px, py, pz, D_Y[1])]
     ins.append(".p2align 6")
     ins += ["s_nop 0"] * pad
@@ -490,7 +494,7 @@ def main():
         for v, pad in ((0, 15), (1, 14)):
             f.write("#define NB_FORCE_LOOP_F64_V%d \"%s\"\n" % (v, "\\n\\t".join(build_f64(pad))))
         f.write("#define NB_FORCE_LOOP_F64_V2 \"%s\"\n" % "\\n\\t".join(build_f64(14, vconst=True)))
-        clob64 = ["v%d" % r for r in range(8, 50)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, D_K375 + 2)] + ["scc", "memory"]
+        clob64 = ["v%d" % r for r in range(8, 52)] + ["s34", "s35"] + ["s%d" % r for r in range(A_BASE, D_K1875 + 2)] + ["scc", "memory"]
         f.write("#define NB_FORCE_LOOP_F64_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob64))
         f.write("#define NB_FORCE_LOOP_F64_GROUP %d\n" % GROUP_F64)
     n_valu = len([i for i in build(11) if i.startswith("v_")])
