@@ -1,7 +1,8 @@
 """The fp64 path against a checked fixture (tests/golden/fp64_n64.json, made by tests/golden/make_fp64.py: the force sum
 evaluated in 60-digit decimal arithmetic and rounded once to binary64 — no code shared with the oracle or the kernels).
 
-There is no strict fp64 mode (1/sqrt is v_rsq_f64 + one third-order step, a few ulp), so the bar is a bound, written here:
+The timed fp64 arithmetic takes the inverse cube from the v_rsq_f64 seed by one third-order step (a few ulp; the strict mode — IEEE sqrt
+and divide, bit-identical to the oracle — is tested at the end of this file and in test_gpu_parity.py), so its bar is a bound, written here:
 every row's force within 8 ulp of that row's largest component (measured on MI355X: 4.0 worst with one wave per segment, 3.0 with 4 or 16).  What a correctly rounded evaluation in sequential order
 costs is measured beside it (the oracle: 7 ulp worst row, 2 median at N = 64) — the bound is about that, far below what a
 missing, doubled or misplaced source would do (a single term is ~2^52 ulp), in every segmentation the engine can take."""

@@ -961,7 +961,7 @@ def test_fp64_strict_bit_exact(nb, oracle_fast, engine_factory):
         op, ov = pos.copy(), vel.copy()
         oracle_fast.step_f64_order(op, ov, 0.01, 1, order_=O.order(nslices=o["nslices"], sub=o["sub"], wsplit=o["wsplit"]))
         assert np.array_equal(bits(p2), bits(op)) and np.array_equal(bits(v2), bits(ov))
-        # the timed fp64 arithmetic (v_rsq_f64 + one third-order step) differs from it by a few ulp of 1/sqrt per pair only
+        # the timed fp64 arithmetic (the inverse cube from the v_rsq_f64 seed by one third-order step) differs from it by a few ulp per pair only
         eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
         fast = eng.forces(pos)
         eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
@@ -997,9 +997,9 @@ def test_fp64_path(nb, oracle_fast, engine_factory):
 
 
 def test_fp64_inverse_square_root_is_accurate_to_a_few_ulp(nb, oracle_fast, engine_factory):
-    """fp64 1/sqrt = v_rsq_f64 seed + one third-order step (rsqrt_f64 in nbody_kernels.hpp).  Two bodies at 400
+    """fp64 inverse cube = v_rsq_f64 seed + one third-order step on the cube (inv3_f64 in nbody_kernels.hpp).  Two bodies at 400
     separations from 1e-6 to 1e3: the pair force d * inv^3 against the oracle's 1.0/sqrt — a few ulp of binary64, i.e.
-    the refinement loses nothing that two Newton steps had."""
+    the six-operation form loses nothing that two Newton steps and a separate cube had."""
     rng = np.random.default_rng(5)
     eng = engine_factory(2, fp64=True)
     worst = 0.0
