@@ -531,6 +531,8 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
       case 16: return launch_isa_f32<16>(L, grid, a);
       case 17: return launch_isa_f32<17>(L, grid, a);
       case 18: return launch_isa_f32<18>(L, grid, a);
+      case 19: return launch_isa_f32<19>(L, grid, a);
+      case 20: return launch_isa_f32<20>(L, grid, a);
 #endif
       default: return launch_isa_f32<1>(L, grid, a);
     }
@@ -1442,7 +1444,7 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_GRAPH: if (value < 0 || value > 256) return NBODY_ERR_ARG; g.opt.graph = value; break;
     case NBODY_OPT_WAVES_PER_SIMD: if (value < 0 || value > 8) return NBODY_ERR_ARG; g.opt.waves_per_simd = value; break;
     case NBODY_OPT_ISA_PHASE:
-      if (value < 0 || value > 18) return NBODY_ERR_ARG;
+      if (value < 0 || value > 20) return NBODY_ERR_ARG;
 #ifndef NBODY_DIAG_LOOPS
       // experiment encodings and timing-only forms (wrong results) are not in the product library: `make diag`
       if (isa_phase_is_diag(value) && !(g.init && g.fp64 && value == 2)) return NBODY_ERR_UNSUPPORTED;

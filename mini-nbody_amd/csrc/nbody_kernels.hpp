@@ -626,7 +626,7 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_s
     } else if constexpr (PLACEMENT == 0) {   // the product loop one 4-byte placement phase off (kept to re-measure that effect)
       NB_RUN_LOOP(NB_FORCE_LOOP_V0, NB_FORCE_LOOP_CLOBBERS);
 #ifdef NBODY_DIAG_LOOPS
-    // `make diag` only (libnbody_hip_diag.so): experiment encodings of the same operations (2, 9..13, 16..18: bit-identical)
+    // `make diag` only (libnbody_hip_diag.so): experiment encodings of the same operations (2, 9..13, 16..20: bit-identical)
     // and TIMING-ONLY forms with WRONG RESULTS (3..8, 14, 15) that price one part of the loop inside the real kernel
     // (tools/gen_force_loop.py, profiles/r02_loop_diagnostics.md).  The product library does not contain them.
     } else if constexpr (PLACEMENT == 2) {
@@ -666,6 +666,10 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_s
       NB_RUN_LOOP(NB_FORCE_LOOP_V17, NB_FORCE_LOOP_DIAG_CLOBBERS);
     } else if constexpr (PLACEMENT == 18) {
       NB_RUN_LOOP(NB_FORCE_LOOP_V18, NB_FORCE_LOOP_DIAG_CLOBBERS);
+    } else if constexpr (PLACEMENT == 19) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V19, NB_FORCE_LOOP_DIAG_CLOBBERS);
+    } else if constexpr (PLACEMENT == 20) {
+      NB_RUN_LOOP(NB_FORCE_LOOP_V20, NB_FORCE_LOOP_DIAG_CLOBBERS);
 #endif
     } else {
       static_assert(PLACEMENT == 1 || LONG, "this loop form exists in the diagnostic build only (make diag)");

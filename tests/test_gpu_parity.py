@@ -314,7 +314,7 @@ for ws in (1, 4, 16):
         ref = eng.forces(pos)
         # (16-wave workgroups exist for the product loop and its placement twin; the other forms would run with 4 waves,
         #  which is another summation order)
-        for phase in ((0,) if ws == 16 else (0, 2, 9, 10, 11, 12, 13, 16, 17, 18)):
+        for phase in ((0,) if ws == 16 else (0, 2, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20)):
             eng.set_option(nb.OPT_ISA_PHASE, phase)
             assert eng.config["variant"] == "isa" and eng.config["isa_phase"] == phase
             assert np.array_equal(eng.forces(pos).view(np.uint32), ref.view(np.uint32)), (ws, jsub, phase)

@@ -95,6 +95,24 @@ def body(k, sbase, b, style="fmaak"):
                 "v_fma_f32 %s, v%d, v%d, %s" % (AX, px, tp, AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, tp, AY),
                 "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, tp, AZ),
                 "v_mul_f32_e64 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e64 v%d, v%d, v%d" % (t, t, U)]
+    if style in ("sdwasub", "e32sub2"):
+        # round 4 experiments on the SGPR-operand surcharge (a VOP3 instruction reading an SGPR costs ~0.9 cycles more on a shared SIMD,
+        # the VOP2 encoding ~0.2, profiles/r02_loop_diagnostics.md), both with the product loop's placement (8-byte units) and eps literal:
+        #   sdwasub   the three subtractions in the SDWA encoding (VOP2 + a selector dword = 8 bytes; gfx9 SDWA takes an SGPR in src0)
+        #   e32sub2   dx and dy as two 4-byte VOP2 (one 8-byte unit), dz as VOP3
+        if style == "sdwasub":
+            sel = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+            out = ["v_sub_f32_sdwa v%d, s%d, %s %s" % (dx, s0, XI, sel), "v_sub_f32_sdwa v%d, s%d, %s %s" % (dy, s0 + 1, YI, sel),
+                   "v_sub_f32_sdwa v%d, s%d, %s %s" % (dz, s0 + 2, ZI, sel)]
+        else:
+            out = ["v_sub_f32_e32 v%d, s%d, %s" % (dx, s0, XI), "v_sub_f32_e32 v%d, s%d, %s" % (dy, s0 + 1, YI), "v_sub_f32_e64 v%d, s%d, %s" % (dz, s0 + 2, ZI)]
+        out.append("v_fmaak_f32 v%d, v%d, v%d, 0x%08x" % (t, dz, dz, SOFT_BITS))
+        out += ["v_fma_f32 v%d, v%d, v%d, v%d" % (t, dy, dy, t), "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dx, dx, t),
+                "v_rsq_f32_e64 v%d, v%d" % (t, t),
+                "v_fma_f32 %s, v%d, v%d, %s" % (AX, px, tp, AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, tp, AY),
+                "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, tp, AZ),
+                "v_mul_f32_e64 v%d, v%d, v%d" % (U, t, t), "v_mul_f32_e64 v%d, v%d, v%d" % (t, t, U)]
+        return out
     if style != "e64":
         sub = "v_sub_f32_e64" if style in ("vgpreps", "subrev", "fmaak") else "v_sub_f32_e32"
         eps = EPS if style == "e32sub_seps" else EPSV
@@ -430,7 +448,7 @@ def check(ins, strict=True):
         op = i.split()[0]
         size = 4 if (op.startswith("s_") and not op.startswith("s_load")) or op.endswith("_e32") else 8
         if op.startswith("v_"):
-            assert op.endswith("_e64") or op.endswith("_e32") or op in ("v_fma_f32", "v_pk_add_f32", "v_fmaak_f32"), i
+            assert op.endswith("_e64") or op.endswith("_e32") or op in ("v_fma_f32", "v_pk_add_f32", "v_fmaak_f32", "v_sub_f32_sdwa"), i
             regs = [int(x) for x in re.findall(r"\bv(\d+)\b", i)]
             regs = regs if op.startswith("v_fmac") else regs[1:]                     # fmac reads its destination
             if len(regs) == 3:
@@ -470,7 +488,8 @@ def main():
             ins = diagnostic(build(15 - HEAD_BYTES // 4), nr, nl)
             assert check(ins) == (60, 4)
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
-        for v, style, strict in ((9, "e32sub", True), (10, "e32sub_nofill", False), (11, "e32all", False), (12, "e64", True), (13, "e32sub_seps", True), (16, "subrev", True), (18, "vgpreps", True)):
+        for v, style, strict in ((9, "e32sub", True), (10, "e32sub_nofill", False), (11, "e32all", False), (12, "e64", True), (13, "e32sub_seps", True), (16, "subrev", True), (18, "vgpreps", True),
+                                 (19, "sdwasub", True), (20, "e32sub2", True)):
             ins = build(15 - HEAD_BYTES // 4, style=style)
             assert check(ins, strict)[0] == 60 and (not strict or check(ins, strict)[1] == 4), (style, check(ins, strict))
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))

@@ -41,7 +41,7 @@ def main():
     vmap = {"smem": nb.VARIANT_SMEM, "lds": nb.VARIANT_LDS, "readlane": nb.VARIANT_READLANE, "isa0": nb.VARIANT_ISA, "isa1": nb.VARIANT_ISA, "isa2": nb.VARIANT_ISA,
             "isa3": nb.VARIANT_ISA, "isa4": nb.VARIANT_ISA, "isa5": nb.VARIANT_ISA,   # isa3..8: timing-only diagnostics
             "isa6": nb.VARIANT_ISA, "isa7": nb.VARIANT_ISA, "isa8": nb.VARIANT_ISA, "isa9": nb.VARIANT_ISA, "isa10": nb.VARIANT_ISA,
-            "isa11": nb.VARIANT_ISA, "isa12": nb.VARIANT_ISA, "isa13": nb.VARIANT_ISA, "isa14": nb.VARIANT_ISA, "isa15": nb.VARIANT_ISA, "isa16": nb.VARIANT_ISA, "isa17": nb.VARIANT_ISA, "isa18": nb.VARIANT_ISA}
+            "isa11": nb.VARIANT_ISA, "isa12": nb.VARIANT_ISA, "isa13": nb.VARIANT_ISA, "isa14": nb.VARIANT_ISA, "isa15": nb.VARIANT_ISA, "isa16": nb.VARIANT_ISA, "isa17": nb.VARIANT_ISA, "isa18": nb.VARIANT_ISA, "isa19": nb.VARIANT_ISA, "isa20": nb.VARIANT_ISA}
     res = {c: [] for c in cfgs}
     for rnd in range(args.rounds):
         for c in cfgs:
