@@ -131,11 +131,27 @@ def cpu_baseline(n, seed, fp64):
 
 
 def kernel_source_sha():
-    """identifies the kernel code a profile was taken on (a profile of an older loop must not be attached to a new one)"""
+    """identifies the PRODUCT kernel code a profile was taken on (a profile of an older loop must not be attached to a new one): the
+    three kernel files with everything under `#ifdef NBODY_DIAG_LOOPS` left out — the experiment encodings of `make diag`
+    (libnbody_hip_diag.so) are not in the product library, and adding one must not orphan the product's profiles"""
     import hashlib
     h = hashlib.sha1()
     for f in ("nbody_kernels.hpp", "force_loop_gfx950.inc", "nbody_hip.hip"):
-        h.update(open(os.path.join(ROOT, "mini-nbody_amd", "csrc", f), "rb").read())
+        skip = 0
+        for line in open(os.path.join(ROOT, "mini-nbody_amd", "csrc", f), "rb").read().splitlines(True):
+            t = line.strip()
+            if skip:
+                if t.startswith(b"#if"):
+                    skip += 1
+                elif t.startswith(b"#endif"):
+                    skip -= 1
+                elif skip == 1 and (t.startswith(b"#else") or t.startswith(b"#elif")):
+                    skip = 0                     # (the product's side of an #ifdef ... #else: hashed)
+                continue
+            if t.startswith(b"#ifdef NBODY_DIAG_LOOPS"):
+                skip = 1
+                continue
+            h.update(line)
     return h.hexdigest()[:12]
 
 

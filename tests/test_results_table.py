@@ -72,3 +72,30 @@ def test_baseline_md_block_is_generated():
         name = r.split("|")[1].strip()
         if name in ("BENCH_r01.json", "BENCH_r02.json", "BENCH_r03.json"):
             assert r in rt.table(ROOT)
+
+
+def test_kernel_source_sha_ignores_the_diagnostic_build(tmp_path, monkeypatch):
+    """bench.kernel_source_sha() keys the committed profiles to the PRODUCT kernel source: text under `#ifdef NBODY_DIAG_LOOPS` (the
+    experiment encodings of `make diag`) is left out, the product's side of an #else is not, and any other change moves the hash"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    d = tmp_path / "mini-nbody_amd" / "csrc"
+    d.mkdir(parents=True)
+    base = {"nbody_kernels.hpp": "int a;\n#ifdef NBODY_DIAG_LOOPS\nint diag1;\n#if X\nint nested;\n#endif\n#endif\nint b;\n",
+            "force_loop_gfx950.inc": "#define P 1\n#ifdef NBODY_DIAG_LOOPS\n#define V19 2\n#endif  // NBODY_DIAG_LOOPS\n",
+            "nbody_hip.hip": "#ifdef NBODY_DIAG_LOOPS\nreturn 1;\n#else\nreturn 0;\n#endif\n#ifndef NBODY_DIAG_LOOPS\nint product_only;\n#endif\n"}
+
+    def sha(files):
+        for k, v in files.items():
+            (d / k).write_text(v)
+        monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+        return bench.kernel_source_sha()
+
+    h0 = sha(base)
+    assert sha(dict(base, **{"nbody_kernels.hpp": base["nbody_kernels.hpp"].replace("int diag1;", "int diag1; int diag2;").replace("int nested;", "")})) == h0
+    assert sha(dict(base, **{"force_loop_gfx950.inc": base["force_loop_gfx950.inc"].replace("#define V19 2", "#define V19 2\n#define V20 3")})) == h0
+    assert sha(dict(base, **{"nbody_hip.hip": base["nbody_hip.hip"].replace("return 1;", "return 2;")})) == h0
+    assert sha(dict(base, **{"nbody_hip.hip": base["nbody_hip.hip"].replace("return 0;", "return 3;")})) != h0          # the product's side of the #else
+    assert sha(dict(base, **{"nbody_hip.hip": base["nbody_hip.hip"].replace("int product_only;", "int product_only2;")})) != h0   # #ifndef: product code
+    assert sha(dict(base, **{"nbody_kernels.hpp": base["nbody_kernels.hpp"].replace("int b;", "int c;")})) != h0
