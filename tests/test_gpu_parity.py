@@ -969,6 +969,31 @@ def test_fp64_strict_bit_exact(nb, oracle_fast, engine_factory):
         assert np.array_equal(bits(fast), bits(strict)) or maxnorm_rel(fast, strict) < 1e-14       # (n = 1: the self pair alone, exactly zero)
 
 
+def test_fp64_strict_virtual_ranks_bit_exact(nb, oracle_fast, engine_factory, monkeypatch):
+    """config 5's decomposition in small: an fp64 job of 3 and of 8 virtual ranks on this GPU (ragged slices), strict arithmetic, the three
+    overlap modes and both combine forms — forces and four steps bit-identical to the oracle in the job's order (one slice per rank x
+    pieces per slice x waves), i.e. the multi-GPU fp64 schedule pinned to the last bit"""
+    monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
+    for ranks, n in ((3, 5000 + 1), (8, 9000 + 5)):
+        pos, vel = nb.make_bodies(n, seed=n, dtype=np.float64)
+        pos[:, :3] += nb.make_bodies(n, seed=n + 1, dtype=np.float64)[0][:, :3] * 2.0 ** -25
+        for overlap, fuse in ((1, 1), (2, 1), (0, 0), (1, 0)):
+            eng = engine_factory(n, fp64=True, ngpus=ranks)
+            eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+            eng.set_option(nb.OPT_OVERLAP, overlap)
+            eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+            o = eng.order
+            assert o["nslices"] == ranks
+            order = O.order(nslices=o["nslices"], sub=o["sub"], wsplit=o["wsplit"])
+            assert np.array_equal(bits(eng.forces(pos)), bits(oracle_fast.forces_f64_order(pos, order_=order))), (ranks, overlap, fuse)
+            eng.upload(pos, vel)
+            eng.step(0.01, 4)
+            gp, gv = eng.download()
+            op, ov = pos.copy(), vel.copy()
+            oracle_fast.step_f64_order(op, ov, 0.01, 4, order_=order)
+            assert np.array_equal(bits(gp), bits(op)) and np.array_equal(bits(gv), bits(ov)), (ranks, overlap, fuse)
+
+
 def test_fp64_path(nb, oracle_fast, engine_factory):
     """BASELINE config 5's arithmetic at a size the host can check: fp64 forces and 5 steps."""
     n = 4096

@@ -341,7 +341,7 @@ def build_pk(pad):
 
 # ---- fp64 (BASELINE config 5's arithmetic): same structure, 19 instructions per pair, all VOP3 (8 bytes) once
 # v_rsq_f64 is written in its 64-bit encoding; 4 sources per iteration (two buffers of 2 bodies x 32 bytes).
-# 1/sqrt = v_rsq_f64 seed + two Newton steps in the 7-operation form of rsqrt_f64() in nbody_kernels.hpp
+# the inverse cube = v_rsq_f64 seed + one third-order step on the cube, the 6-operation form of inv3_f64() in nbody_kernels.hpp (body_f64 below)
 #   hx = x/2;  r = hx*y; e = fma(-r, y, 1/2); y = fma(y, e, y)   (twice)
 D_T, D_HX, D_R, D_E, D_U = 32, 38, 40, 42, 44
 D_Y = [34, 36]
