@@ -339,10 +339,9 @@ def build_pk(pad):
         DSETS, AX = keep
 
 
-# ---- fp64 (BASELINE config 5's arithmetic): same structure, 19 instructions per pair, all VOP3 (8 bytes) once
-# v_rsq_f64 is written in its 64-bit encoding; 4 sources per iteration (two buffers of 2 bodies x 32 bytes).
+# ---- fp64 (BASELINE config 5's arithmetic): same structure, 16 instructions per pair (round 1: 19, rounds 2-3: 17), all VOP3 (8 bytes)
+# once v_rsq_f64 is written in its 64-bit encoding; 4 sources per iteration (two buffers of 2 bodies x 32 bytes).
 # the inverse cube = v_rsq_f64 seed + one third-order step on the cube, the 6-operation form of inv3_f64() in nbody_kernels.hpp (body_f64 below)
-#   hx = x/2;  r = hx*y; e = fma(-r, y, 1/2); y = fma(y, e, y)   (twice)
 D_T, D_HX, D_R, D_E, D_U = 32, 38, 40, 42, 44
 D_Y = [34, 36]
 D_DSETS = [(20, 22, 24), (26, 28, 30)]
