@@ -21,7 +21,12 @@ def pytest_sessionstart(session):
     need = [os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"),
             os.path.join(ROOT, "oracle", "libnbody_ref.so"), os.path.join(ROOT, "oracle", "libnbody_ref_fast.so"),
             os.path.join(ROOT, "oracle", "nbody_cpu"), os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip_diag.so")]
-    if all(os.path.exists(p) for p in need):
+    # ... and again whenever a source is newer than what was built from it: a stale library must not be what the tests (or a gpurun
+    # snapshot, which ships the built files) exercise
+    src = [os.path.join(ROOT, "mini-nbody_amd", "csrc", f) for f in ("nbody_hip.hip", "nbody_kernels.hpp", "force_loop_gfx950.inc")] + \
+          [os.path.join(ROOT, "include", "nbody.h"), os.path.join(ROOT, "oracle", "nbody_ref.c"), os.path.join(ROOT, "oracle", "nbody_ref.h"),
+           os.path.join(ROOT, "oracle", "nbody_cpu.c"), os.path.join(ROOT, "mini-nbody_amd", "host", "nbody.c")]
+    if all(os.path.exists(p) for p in need) and max(os.path.getmtime(p) for p in src) <= min(os.path.getmtime(p) for p in need):
         return
     r = subprocess.run(["make", "lib", "diag", "host", "oracle"], cwd=ROOT, capture_output=True, text=True)
     if r.returncode != 0:
