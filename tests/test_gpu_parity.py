@@ -1231,3 +1231,27 @@ def test_rccl_calls_on_a_one_rank_communicator(nb, engine_factory):
         plain.comm_selftest()
     f64 = engine_factory(2001, fp64=True, rank=0, nranks=1, uid=nb.unique_id())
     assert f64.comm_selftest() == (2001 // 2) * 32
+
+
+def test_rate_floors_of_the_timed_kernels(nb, engine_factory, capsys):
+    """A guard against silent performance regressions (a loop assembled one placement phase off loses 28 %, an extra VGPR an eighth
+    of the resident waves): HIP-event time of the force kernel in the engine's own configuration.  Floors sit 8-10 % under the slowest
+    box met in four rounds (fp32 N = 1M: 4476 G pairs/s; fp32 N = 65536: 4480; fp64 N = 262144 with the 16-instruction loop: 1926)."""
+    seen = {}
+    for name, n, fp64, steps, floor in (("fp32 N=1048576", 1 << 20, False, 2, 4100.0), ("fp32 N=65536", 65536, False, 50, 4050.0),
+                                        ("fp64 N=262144", 262144, True, 3, 1750.0)):
+        pos, vel = nb.make_bodies(n, dtype=np.float64 if fp64 else np.float32)
+        eng = engine_factory(n, fp64=fp64)
+        eng.upload(pos, vel)
+        eng.set_option(nb.OPT_TIMING, 1)
+        eng.step(0.01, 1)
+        eng.sync()
+        eng.kernel_time(reset=True)
+        eng.step(0.01, steps)
+        eng.sync()
+        ms, launches = eng.kernel_time(reset=True)
+        rate = float(n) * n * steps / (ms * 1e-3) / 1e9
+        seen[name] = rate
+        assert launches == steps and rate >= floor, (name, rate, floor)
+    with capsys.disabled():
+        print("\n[rate floors] " + "; ".join("%s: %.0f G pairs/s" % kv for kv in seen.items()))
