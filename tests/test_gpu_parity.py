@@ -1236,9 +1236,9 @@ def test_rccl_calls_on_a_one_rank_communicator(nb, engine_factory):
 def test_rate_floors_of_the_timed_kernels(nb, engine_factory, capsys):
     """A guard against silent performance regressions (a loop assembled one placement phase off loses 28 %, an extra VGPR an eighth
     of the resident waves): HIP-event time of the force kernel in the engine's own configuration.  Floors sit 8-10 % under the slowest
-    box met in four rounds (fp32 N = 1M: 4476 G pairs/s; fp32 N = 65536: 4480; fp64 N = 262144 with the 16-instruction loop: 1926)."""
+    box met in four rounds (fp32 N = 1M: 4476 G pairs/s; fp32 N = 65536: 4480 untimed, ~4270 with an event pair around every 0.94-ms launch; fp64 N = 262144 with the 16-instruction loop: 1926)."""
     seen = {}
-    for name, n, fp64, steps, floor in (("fp32 N=1048576", 1 << 20, False, 2, 4100.0), ("fp32 N=65536", 65536, False, 50, 4050.0),
+    for name, n, fp64, steps, floor in (("fp32 N=1048576", 1 << 20, False, 2, 4100.0), ("fp32 N=65536", 65536, False, 50, 3800.0),
                                         ("fp64 N=262144", 262144, True, 3, 1750.0)):
         pos, vel = nb.make_bodies(n, dtype=np.float64 if fp64 else np.float32)
         eng = engine_factory(n, fp64=fp64)
