@@ -23,7 +23,8 @@ left of it minus a reserve for the attempts still to come, so that every fallbac
 The line says what ran in machine-readable fields — transport_used, fallback_from, fallback_reason, attempts[{transport,
 seconds, result}] — and --no-fallback turns a failure of the requested transport into exit code 3 instead of a retry (for
 scaling runs where a peer-copy number must not pass as the RCCL point).  Workers run the library's transport self-test
-(nbody_comm_selftest: every received word checked) before the warm-up.
+(nbody_comm_selftest: every received word checked) before the warm-up.  NBODY_VIRTUAL_HOSTS=1 in the environment rehearses an N-rank RCCL
+job on a box with fewer GPUs: every rank poses as its own host (NCCL_HOSTID) and RCCL connects them over loopback sockets.
 
 Extras (N > 1 only; the N = 1 path is untouched).  Rank 0 prints the headline line FIRST; then, in the same worker
 processes, (a) three steps each of NBODY_COMM_RING with one launch per arriving slice, NBODY_COMM_DIRECT and
@@ -237,6 +238,11 @@ def start_worker(cmd, rank, local, world, port, transport, logdir, attempt, extr
     for k in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
         env.pop(k, None)
     env.pop("OMP_NUM_THREADS", None)      # torch.distributed.run pins it to 1; the CPU-baseline leg wants the host's cores
+    if env.get("NBODY_VIRTUAL_HOSTS"):
+        # rehearsal on a box with fewer GPUs than ranks: every rank poses as a host of its own (RCCL compares host id and PCI bus id before
+        # it refuses a second rank on one device) and RCCL connects the ranks through its socket transport over loopback — the real multi-rank
+        # RCCL path (communicator of N ranks, ncclAllGather, grouped ncclSend/ncclRecv, streams, events, the hand-shake) without a second GPU
+        env.update({"NCCL_HOSTID": "nbody-virtual-host-%d" % rank, "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1", "NBODY_OVERSUBSCRIBE": "1"})
     if extra_env:
         env.update(extra_env)
     env[READY_ENV] = os.path.join(logdir, "a%d_rank%d.ready" % (attempt, rank))

@@ -220,3 +220,73 @@ def test_bench_under_torch_distributed_run(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["finite"]
     assert out["transport_used"] == "peer" and out["fallback_from"] == "rccl" and [a["transport"] for a in out["attempts"]] == ["rccl", "peer"]
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0 and set(out["comm_forms"]) == {"peer"} and "extras" not in out
+
+
+def virtual_host_env(rank):
+    """several RCCL ranks on ONE device: each poses as a host of its own (RCCL compares host id and bus id before refusing a duplicate GPU)
+    and RCCL connects them through its socket transport over loopback"""
+    return {"NCCL_HOSTID": "nbody-virtual-host-%d" % rank, "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1"}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_real_rccl_ranks_on_one_gpu_over_loopback(nb, tmp_path, world):
+    """ADVICE r03, answered on the one-GPU box after all: a REAL multi-rank RCCL job — `world` processes, ncclCommInitRank over `world` ranks,
+    ncclAllGather / grouped ncclSend + ncclRecv between different ranks, the second stream, the per-slice events, the hand-shake — with the
+    ranks sharing this box's one GPU and posing as separate hosts so that RCCL links them by loopback sockets instead of refusing the
+    duplicate device.  Every transfer form and overlap mode, ragged N: the self-test checks every received word, and forces, positions and
+    velocities after 4 steps equal the one-GPU restatement of the job's summation order bit for bit."""
+    for comm_name, overlap in (("auto", 1), ("auto", 0), ("ring", 2), ("ring", 1), ("direct", 1), ("direct", 2), ("allgather", 1)):
+        comm = {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "direct": nb.COMM_DIRECT, "allgather": nb.COMM_ALLGATHER}[comm_name]
+        n, steps, jsub = 30000 + 7, 4, 2
+        out = str(tmp_path / ("lo_%s_%d" % (comm_name, overlap)))
+        script = tmp_path / ("worker_%s_%d.py" % (comm_name, overlap))
+        script.write_text(WORKER.format(root=ROOT, n=n, steps=steps, jsub=jsub, overlap=overlap, out=out, transport="rccl", comm=comm))
+        port = free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       NBODY_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", **virtual_host_env(r))
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0, (comm_name, overlap, o.decode()[-3000:])
+        pos, vel = nb.make_bodies(n, seed=33)
+        one = nb.NBody(n)
+        try:
+            one.set_option(nb.OPT_JSUB, jsub)
+            one.set_option(nb.OPT_JSLICES, world)
+            one.set_option(nb.OPT_WSPLIT, int(open(out + "_wsplit.txt").read()))
+            wf = one.forces(pos)
+            one.upload(pos, vel)
+            one.step(0.01, steps)
+            wp, wv = one.download()
+        finally:
+            one.close()
+        assert np.array_equal(np.load(out + "_pos.npy").view(np.uint32), wp.view(np.uint32)), (comm_name, overlap)
+        assert np.array_equal(np.load(out + "_vel.npy").view(np.uint32), wv.view(np.uint32)), (comm_name, overlap)
+        assert np.array_equal(np.load(out + "_force.npy").view(np.uint32), wf.view(np.uint32)), (comm_name, overlap)
+
+
+def test_bench_rccl_attempt_with_virtual_hosts(tmp_path):
+    """`NBODY_VIRTUAL_HOSTS=1 python bench.py --gpus 2`: the supervised RCCL attempt itself succeeds on this box — two worker processes, one
+    RCCL communicator of two ranks, the transfer self-test, the timed steps with the all-gather on the second stream — so the line says
+    transport_used rccl with no fallback, and the extras pass measures the three transfer forms and the fp64 configuration over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NBODY_VIRTUAL_HOSTS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "262144", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--extras", "all", "--config5-bodies", "65536", "--autotune"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["finite"]
+    assert out["transport_used"] == "rccl" and out["fallback_from"] is None and [a["transport"] for a in out["attempts"]] == ["rccl"]
+    assert "/ rccl /" in out["config"]["comm"] and "autotuned in warm-up" in out["config"]["comm"]
+    assert set(out["comm_forms"]) == {"allgather", "direct", "ring"} and all(e["ms_per_step"] > 0 for e in out["comm_forms"].values())
+    assert out["comm_forms"]["ring"]["form_resolved"] == "ring" and out["comm_forms"]["ring"]["overlap"] == 2
+    assert out["config5"]["value"] > 0 and out["config5"]["kernel"]["n_local"] == 32768 and "extras" not in out
+    assert out["comm_exposed_ms_per_step"] >= 0 and out["config"]["kernel"]["nranks"] == 2
