@@ -1022,13 +1022,13 @@ def test_fp64_path(nb, oracle_fast, engine_factory):
 
 
 def test_fp64_inverse_square_root_is_accurate_to_a_few_ulp(nb, oracle_fast, engine_factory):
-    """fp64 inverse cube = v_rsq_f64 seed + one third-order step on the cube (inv3_f64 in nbody_kernels.hpp).  Two bodies at 400
+    """fp64 inverse cube = v_rsq_f64 seed + one third-order step on the cube (inv3_f64 in nbody_kernels.hpp).  Two bodies at 150
     separations from 1e-6 to 1e3: the pair force d * inv^3 against the oracle's 1.0/sqrt — a few ulp of binary64, i.e.
     the six-operation form loses nothing that two Newton steps and a separate cube had."""
     rng = np.random.default_rng(5)
     eng = engine_factory(2, fp64=True)
     worst = 0.0
-    for k in range(400):
+    for k in range(150):
         sep = 10.0 ** rng.uniform(-6, 3)
         d = rng.normal(size=3)
         d *= sep / np.linalg.norm(d)
