@@ -45,7 +45,8 @@ Rank 0 prints ONE JSON line, always with:
                 (profiles/pmc_*.json, tools/profile.sh) and are attached only when that profile's recorded
                 configuration equals the run's; otherwise `traffic` is null.
   cpu_baseline  the oracle (oracle/nbody_ref.c, kind "port": the reference is VHDL and has no CPU path) timed on
-                this box's host cores, rank 0, after the timed region, on a bounded row sample.
+                this box's host cores, rank 0, after the timed region, on a bounded row sample — at N = 1; an N > 1 line
+                carries the object with value null (--cpu-baseline always times it there too).
 and for N > 1: comm_exposed_ms_per_step — how long per step the compute stream sat waiting for arriving position slices
 (HIP events around every such wait; 0 = the transfers hid behind the own-slice kernel).
 """
@@ -552,7 +553,10 @@ def main(argv=None):
     ap.add_argument("--sum", choices=["blocked", "seq"], default="blocked")
     ap.add_argument("--sum-block", type=int, default=0)
     ap.add_argument("--fuse", type=int, default=-1, help="1: one launch per step (in-launch combine), 0: two, -1: auto")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline never")
+    ap.add_argument("--cpu-baseline", choices=["auto", "always", "never"], default="auto",
+                    help="the oracle timed on this box's host cores after the timed region, rank 0: auto = at N = 1 only (the contract: a bounded "
+                         "sample, N = 1 only — and at N > 1 the headline line is out 10-25 s sooner); always: also at N > 1")
     ap.add_argument("--comm", choices=["auto", "ring", "allgather", "direct"], default="auto")
     ap.add_argument("--transport", choices=["auto", "rccl", "peer", "host"], default="auto",
                     help="how positions travel between GPUs: rccl (one process per GPU, RCCL over xGMI; auto = rccl, falling back to host when "
@@ -807,7 +811,11 @@ def main(argv=None):
     if eng is not None and not extras:
         eng.close()
     if rank == 0:
-        if not args.no_cpu_baseline:
+        cpu_leg = not args.no_cpu_baseline and (args.cpu_baseline == "always" or (args.cpu_baseline == "auto" and world == 1))
+        if not cpu_leg and not args.no_cpu_baseline and args.cpu_baseline != "never":
+            out["cpu_baseline"] = {"value": None, "unit": "billion pair-interactions/s", "cores": 0, "kind": "port",
+                                   "sample": "not timed at N > 1: the host-CPU baseline is the N = 1 run's (same box class, same workload); --cpu-baseline always times it here too"}
+        if cpu_leg:
             # after the timed region (one GPU: with the GPU context closed); the other ranks wait at the barrier below, idle
             try:
                 out["cpu_baseline"] = cpu_baseline(n, args.seed, args.fp64)
