@@ -65,13 +65,24 @@ def test_baseline_md_block_is_generated():
     s = open(os.path.join(ROOT, "BASELINE.md")).read()
     assert rt.BEGIN in s and rt.END in s
     block = s[s.index(rt.BEGIN) + len(rt.BEGIN):s.index(rt.END)].strip()
-    have = {r.split("|")[1].strip() for r in block.splitlines()[2:]}
+    rows = [r for r in block.splitlines() if r.startswith("| ")]
+    have = {r.split("|")[1].strip() for r in rows}
     want = {r[0] for r in rt.records(ROOT)}
-    assert want <= have | {n for n in want if n.endswith("r04.json") or int(n.split("_r")[1][:2]) > 3}    # records newer than the commit are the driver's
-    for r in block.splitlines()[2:]:
+    assert want <= have | {n for n in want if int(n.split("_r")[1][:2]) > 3}    # records newer than the commit are the driver's
+    assert {"1", "2", "4", "8"} <= have                                          # the short form: one row per GPU count
+    for r in rows:
         name = r.split("|")[1].strip()
         if name in ("BENCH_r01.json", "BENCH_r02.json", "BENCH_r03.json"):
             assert r in rt.table(ROOT)
+
+
+def test_latest_table_picks_the_newest_line_per_gpu_count(tmp_path):
+    json.dump({"parsed": line(1, 4600.0)}, open(tmp_path / "BENCH_r03.json", "w"))
+    json.dump({"parsed": line(1, 4700.0)}, open(tmp_path / "BENCH_r04.json", "w"))
+    json.dump({"runs": [{"parsed": line(1, 4710.0)}, {"parsed": line(2, 9300.0)}, {"parsed": line(8, 36000.0)}]}, open(tmp_path / "SCALE_r04.json", "w"))
+    t = rt.latest_table(str(tmp_path)).splitlines()
+    assert t[2].startswith("| 1 | SCALE_r04.json | 4710 |") and t[3].startswith("| 2 | SCALE_r04.json | 9300 | 59.0 | 0.987 |")
+    assert "not measured yet" in t[4] and t[5].startswith("| 8 | SCALE_r04.json | 36000 | 59.0 | 0.955 |")
 
 
 def test_kernel_source_sha_ignores_the_diagnostic_build(tmp_path, monkeypatch):
