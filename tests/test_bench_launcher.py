@@ -35,7 +35,10 @@ STUB = textwrap.dedent('''
     if mode == "noready" and transport not in ("host", "peer"):
         time.sleep(3600)
     line = {"metric": "stub", "n_gpus": world, "config": {"comm": "allgather / %s / overlap 1" % {"host": "host-staged", "peer": "peer copies"}.get(transport, "rccl")},
-            "env": {k: os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}, "argv": sys.argv[1:]}
+            "env": {k: os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "NCCL_HOSTID", "NCCL_SOCKET_IFNAME", "NBODY_OVERSUBSCRIBE") if k in os.environ},
+            "argv": sys.argv[1:]}
+    if os.environ.get("STUB_HOSTID_DIR"):
+        open(os.path.join(os.environ["STUB_HOSTID_DIR"], "rank%d" % rank), "w").write(os.environ.get("NCCL_HOSTID", ""))
     if rank == 0:
         print("noise before the line")
         print(json.dumps(line), flush=True)
@@ -287,3 +290,17 @@ def test_an_extra_that_hangs_keeps_the_extras_finished_before_it(stub):
     code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=600, extras_s=1.5, extra_env={"STUB_MODE": "extraspartial"})
     assert code == 0 and obj["metric"] == "stub" and "argv" in obj
     assert obj["comm_forms"] == {"allgather": {"ms_per_step": 30.5}} and obj["extras"].startswith("timed out")
+
+
+def test_virtual_hosts_give_every_rank_its_own_host_identity(stub, tmp_path, monkeypatch):
+    """NBODY_VIRTUAL_HOSTS=1 (rehearsal of an N-rank RCCL job on fewer GPUs): every worker gets a different NCCL_HOSTID, loopback as
+    RCCL's socket interface and leave to share a device; without it none of these is set"""
+    monkeypatch.delenv("NCCL_HOSTID", raising=False)
+    monkeypatch.delenv("NBODY_VIRTUAL_HOSTS", raising=False)
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extra_env={"STUB_MODE": "ok"})
+    assert code == 0 and "NCCL_HOSTID" not in obj["env"]
+    monkeypatch.setenv("NBODY_VIRTUAL_HOSTS", "1")
+    code, obj = bench.supervise(stub, 3, [0, 1, 2], "auto", deadline_s=60, extra_env={"STUB_MODE": "ok", "STUB_HOSTID_DIR": str(tmp_path)})
+    assert code == 0 and obj["env"]["NCCL_HOSTID"] == "nbody-virtual-host-0" and obj["env"]["NCCL_SOCKET_IFNAME"] == "lo" and obj["env"]["NBODY_OVERSUBSCRIBE"] == "1"
+    ids = {open(tmp_path / ("rank%d" % r)).read() for r in range(3)}
+    assert ids == {"nbody-virtual-host-0", "nbody-virtual-host-1", "nbody-virtual-host-2"}
