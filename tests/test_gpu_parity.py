@@ -994,6 +994,24 @@ def test_fp64_strict_bit_exact(nb, oracle_fast, engine_factory):
         assert np.array_equal(bits(fast), bits(strict)) or maxnorm_rel(fast, strict) < 1e-14       # (n = 1: the self pair alone, exactly zero)
 
 
+def test_fp64_strict_every_row_at_the_profiled_size(nb, oracle_fast, engine_factory):
+    """fp64 N = 262144 — the size the fp64 rocprofv3 profiles and bench lines are taken at — in the engine's own configuration (8 segments x 4
+    pieces): strict arithmetic bit-identical to the oracle on every row (6.9e10 pairs on the host), and the timed arithmetic (the 16-instruction
+    loop) within 1e-13 of it on every row, relative to that row's own force"""
+    n = 262144
+    pos, _ = nb.make_bodies(n, dtype=np.float64)
+    pos[:, :3] += nb.make_bodies(n, seed=7, dtype=np.float64)[0][:, :3] * 2.0 ** -25
+    eng = engine_factory(n, fp64=True)
+    assert eng.config["variant"] == "isa"
+    fast = eng.forces(pos)
+    o = eng.order
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    assert eng.order == o and eng.config["variant"] == "smem"
+    want = oracle_fast.forces_f64_order(pos, order_=O.order(nslices=o["nslices"], sub=o["sub"], wsplit=o["wsplit"]))
+    assert np.array_equal(bits(eng.forces(pos)), bits(want))
+    assert row_rel(fast, want).max() < 1e-13
+
+
 def test_fp64_strict_virtual_ranks_bit_exact(nb, oracle_fast, engine_factory, monkeypatch):
     """config 5's decomposition in small: an fp64 job of 3 and of 8 virtual ranks on this GPU (ragged slices), strict arithmetic, the three
     overlap modes and both combine forms — forces and four steps bit-identical to the oracle in the job's order (one slice per rank x
