@@ -29,7 +29,7 @@ job on a box with fewer GPUs: every rank poses as its own host (NCCL_HOSTID) and
 Extras (N > 1 only; the N = 1 path is untouched).  Rank 0 prints the headline line FIRST; then, in the same worker
 processes, (a) three steps each of NBODY_COMM_RING with one launch per arriving slice, NBODY_COMM_DIRECT and
 NBODY_COMM_ALLGATHER -> "comm_forms": {form: {ms_per_step, comm_exposed_ms_per_step, value}} (ring
-against direct over xGMI), and (b) at N = 8 BASELINE configs[4]: an fp64 N = 4,194,304 engine, 1 warm-up + 2 timed steps ->
+against direct over xGMI) plus the all-gather with no overlap, whose exposed time is the transfer's own duration, and (b) at N = 8 BASELINE configs[4]: an fp64 N = 4,194,304 engine, 1 warm-up + 2 timed steps ->
 "config5": {value, ms_per_step, roofline, hbm_gb_per_s, comm_exposed_ms_per_step}; then a second line = headline + extras,
 after every finished extra rank 0 prints one more line = headline + extras so far, and the supervisor takes the LAST complete line.
 The extras have their own deadline (--extras-deadline, 90 s after the first line appeared): past it the workers are killed and that
@@ -848,7 +848,10 @@ def comm_forms_pass(eng, nb, args, n, transport, run_timed, publish, steps=3):
     Transports without forms (peer copies, host-staged) give one entry.  Every rank takes part (eng None: collectives only)."""
     if transport == "rccl":
         # in ascending order of novelty: the all-gather is what the headline just ran; the ring's P-1 dependent groups come last
-        forms = [("allgather", nb.COMM_ALLGATHER, 1), ("direct", nb.COMM_DIRECT, 1), ("ring", nb.COMM_RING, 2)]
+        forms = [("allgather", nb.COMM_ALLGATHER, 1), ("direct", nb.COMM_DIRECT, 1), ("ring", nb.COMM_RING, 2),
+                 # ... and the all-gather with NO overlap (gather first, then one launch): its comm_exposed_ms_per_step IS the transfer's
+                 # duration on this job's links, the number the overlapped forms are hiding
+                 ("allgather_gather_first", nb.COMM_ALLGATHER, 0)]
     else:
         forms = [("peer" if transport.startswith("peer") else "host", None, args.overlap)]
     res = {}

@@ -225,7 +225,7 @@ def test_bench_under_torch_distributed_run(tmp_path, virtual_hosts):
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] is None and "N = 1" in out["cpu_baseline"]["sample"] and "extras" not in out
     if virtual_hosts:
         assert out["transport_used"] == "rccl" and out["fallback_from"] is None and [a["transport"] for a in out["attempts"]] == ["rccl"]
-        assert set(out["comm_forms"]) == {"allgather", "direct", "ring"} and "/ rccl /" in out["config"]["comm"]
+        assert set(out["comm_forms"]) == {"allgather", "direct", "ring", "allgather_gather_first"} and "/ rccl /" in out["config"]["comm"]
     else:
         assert out["transport_used"] == "peer" and out["fallback_from"] == "rccl" and [a["transport"] for a in out["attempts"]] == ["rccl", "peer"]
         assert set(out["comm_forms"]) == {"peer"}
@@ -297,7 +297,8 @@ def test_bench_rccl_attempt_with_virtual_hosts(tmp_path):
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["finite"]
     assert out["transport_used"] == "rccl" and out["fallback_from"] is None and [a["transport"] for a in out["attempts"]] == ["rccl"]
     assert "/ rccl /" in out["config"]["comm"] and "autotuned in warm-up" in out["config"]["comm"]
-    assert set(out["comm_forms"]) == {"allgather", "direct", "ring"} and all(e["ms_per_step"] > 0 for e in out["comm_forms"].values())
+    assert set(out["comm_forms"]) == {"allgather", "direct", "ring", "allgather_gather_first"} and all(e["ms_per_step"] > 0 for e in out["comm_forms"].values())
+    assert out["comm_forms"]["allgather_gather_first"]["overlap"] == 0 and out["comm_forms"]["allgather_gather_first"]["comm_exposed_ms_per_step"] > 0
     assert out["comm_forms"]["ring"]["form_resolved"] == "ring" and out["comm_forms"]["ring"]["overlap"] == 2
     assert out["config5"]["value"] > 0 and out["config5"]["kernel"]["n_local"] == 32768 and "extras" not in out
     assert out["comm_exposed_ms_per_step"] >= 0 and out["config"]["kernel"]["nranks"] == 2
