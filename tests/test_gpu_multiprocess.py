@@ -248,7 +248,7 @@ def test_real_rccl_ranks_on_one_gpu_over_loopback(nb, tmp_path, world):
             (("auto", 1), ("ring", 2), ("direct", 1), ("allgather", 0))
     for comm_name, overlap in forms:
         comm = {"auto": nb.COMM_AUTO, "ring": nb.COMM_RING, "direct": nb.COMM_DIRECT, "allgather": nb.COMM_ALLGATHER}[comm_name]
-        n, steps, jsub = 30000 + 7, 4, 2
+        n, steps, jsub = 30000 + 7, int(os.environ.get("NBODY_TEST_RCCL_STEPS", "4")), 2      # (a soak sets the step count: profiles/r04_rccl_soak.txt)
         out = str(tmp_path / ("lo_%s_%d" % (comm_name, overlap)))
         script = tmp_path / ("worker_%s_%d.py" % (comm_name, overlap))
         script.write_text(WORKER.format(root=ROOT, n=n, steps=steps, jsub=jsub, overlap=overlap, out=out, transport="rccl", comm=comm, fp64=False))
