@@ -32,6 +32,7 @@ SYMBOLS = [
     "nbody_forces_d", "nbody_forces_rows", "nbody_mailbox_run", "nbody_kernel_time", "nbody_device_ptr",
     "nbody_set_host_gather", "nbody_download_slice", "nbody_comm_selftest", "nbody_forces_rows_d",
     "nbody_comm_selftest_virtual", "nbody_comm_plan", "nbody_comm_probe", "nbody_comm_time",
+    "nbody_rsqrt_selftest", "nbody_rsqrt_strict",
 ]
 
 
@@ -80,6 +81,8 @@ def load():
         "nbody_mailbox_run": [vp, vp, i], "nbody_kernel_time": [C.POINTER(d), C.POINTER(C.c_longlong), i],
         "nbody_device_ptr": [i, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "nbody_set_host_gather": [HOST_GATHER_FN, vp], "nbody_download_slice": [vp, vp],
+        "nbody_rsqrt_selftest": [C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)],
+        "nbody_rsqrt_strict": [fp, fp, i, i],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

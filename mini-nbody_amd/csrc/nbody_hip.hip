@@ -1418,6 +1418,50 @@ int nbody_comm_probe(long long bytes, int when, double* comm_ms, double* force_m
   return NBODY_OK;
 }
 
+// The strict 1/sqrt (NBODY_ARITH_STRICT, fp32) checked against its own definition on the device that will run it: needs no context.
+static int rsqrt_device() {
+  if (g.init) return g.loc[0].device;
+  int ndev = 0;
+  if (device_count(&ndev)) return -1;
+  return pick_device(0, ndev);
+}
+struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } };
+
+int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned long long* mismatches, unsigned long long* ieee_lanes, unsigned* first_bad) {
+  if (count == 0 || count > (1ull << 32) || (unsigned long long)first_bits + count > (1ull << 32)) return NBODY_ERR_ARG;
+  const int dev = rsqrt_device();
+  if (dev < 0) return NBODY_ERR_NO_DEVICE;
+  HIPC(hipSetDevice(dev));
+  DevBuf out;
+  HIPC(hipMalloc(&out.p, 3 * sizeof(unsigned long long)));
+  const unsigned long long zero[3] = {0, 0, ~0ull};
+  HIPC(hipMemcpy(out.p, zero, sizeof(zero), hipMemcpyHostToDevice));
+  const unsigned long long wgs = (count + 255) / 256;
+  rsqrt_selftest_kernel<<<dim3((unsigned)(wgs < 16384 ? wgs : 16384)), dim3(256)>>>(first_bits, count, (unsigned long long*)out.p);
+  HIPC(hipGetLastError());
+  unsigned long long res[3];
+  HIPC(hipMemcpy(res, out.p, sizeof(res), hipMemcpyDeviceToHost));
+  if (mismatches) *mismatches = res[0];
+  if (ieee_lanes) *ieee_lanes = res[1];
+  if (first_bad) *first_bad = res[0] ? (unsigned)res[2] : 0u;
+  return NBODY_OK;
+}
+
+int nbody_rsqrt_strict(const float* x, float* y, int n, int ieee_only) {
+  if (!x || !y || n <= 0) return NBODY_ERR_ARG;
+  const int dev = rsqrt_device();
+  if (dev < 0) return NBODY_ERR_NO_DEVICE;
+  HIPC(hipSetDevice(dev));
+  DevBuf dx, dy;
+  HIPC(hipMalloc(&dx.p, (size_t)n * sizeof(float)));
+  HIPC(hipMalloc(&dy.p, (size_t)n * sizeof(float)));
+  HIPC(hipMemcpy(dx.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  rsqrt_array_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>((const float*)dx.p, (float*)dy.p, n, ieee_only ? 1 : 0);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpy(y, dy.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return NBODY_OK;
+}
+
 void nbody_shutdown(void) {
   drop_step_graph();
   for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);

@@ -137,6 +137,68 @@ __device__ __forceinline__ float soft_f32() { return __builtin_bit_cast(float, k
 // bit 1: "strict" 1/sqrt, rounded once from an fp64 evaluation with IEEE sqrt and divide — the same
 // value oracle/nbody_ref.c computes (REF_RSQRT_F64), so a strict run matches the oracle bit for bit.
 constexpr int kArithRef = 1, kArithStrict = 2;
+
+// The strict 1/sqrt as the oracle writes it (oracle/nbody_ref.c REF_RSQRT_F64): IEEE square root and divide in binary64, rounded once to
+// binary32.  About 150 issue cycles per wave.
+__device__ __forceinline__ float rsqrt_ieee_f32(float x) { return (float)(1.0 / __builtin_sqrt((double)x)); }
+
+// The same VALUE from nine binary32 operations for all but ~2^-16 of the arguments (round 4).  y = v_rsq_f32(x) is within 1 ulp, so the
+// answer is y or a neighbour: with e = 1 - x y^2 (|e| < 2^-21), x^(-1/2) = y (1 - e)^(-1/2) = y + y e/2 + y 3e^2/8 + ..., and ONE fma
+// y + (y/2) e rounds the corrected value to binary32 correctly — provided e is known to ~2^-43, which binary32 delivers because the
+// product x y is carried as an exact pair (hi + lo = x y, an fma's error term) and 1 - hi y, - lo y are both tiny: each fma rounds at
+// <= 2^-46.  What is neglected (3e^2/8 <= 2^-44.4, the roundings of e, the oracle's own two binary64 roundings <= 2^-51.5) moves the
+// value by < 2^-43 y, which can only change the rounding if it lies that close to the midpoint of two binary32 neighbours.  That case is
+// DETECTED, not assumed away: the final fma is evaluated twice, with y/2 widened and narrowed by 2^-16 (a band of >= 2^-41 y about the
+// correction where a midpoint can matter, 4x what is neglected even for a 2-ulp seed); rounding is monotone, so if both give the same
+// binary32 every value between them does, the oracle's included.  Where they differ (about 2^-16 of arguments; also every NaN, since a NaN
+// compares unequal to itself: x = inf, NaN or negative) the wave computes the IEEE form — one wave in ~1000 per source.  The seed's
+// accuracy is part of the contract (a seed off by 2^-20 ... 2^-9 would pass the band with a wrong value: tests/test_strict_rsqrt.py
+// test_model_limits), so it is proved on the hardware rather than on paper: nbody_rsqrt_selftest() compares this with rsqrt_ieee_f32
+// for EVERY binary32 bit pattern (tests/test_strict_rsqrt.py, -m gpu).
+constexpr float kStrictBand = 0x1p-16f;
+__device__ __forceinline__ bool rsqrt_fast_f32(float x, float& r) {   // true: r is the strict value; false: r is unspecified
+  float y = __builtin_amdgcn_rsqf(x);
+  float hi = x * y;
+  float lo = __builtin_fmaf(x, y, -hi);
+  float e = __builtin_fmaf(-hi, y, 1.0f);
+  e = __builtin_fmaf(-lo, y, e);
+  r = __builtin_fmaf(y * (0.5f + kStrictBand), e, y);
+  float r2 = __builtin_fmaf(y * (0.5f - kStrictBand), e, y);
+  return r == r2;
+}
+__device__ __forceinline__ float rsqrt_strict_f32(float x) {
+  float r;
+  bool ok = rsqrt_fast_f32(x, r);
+  if (__builtin_amdgcn_ballot_w64(!ok) != 0) {      // wave-uniform: no lane pays for the IEEE form unless one of the 64 needs it
+    float s = rsqrt_ieee_f32(x);
+    r = ok ? r : s;
+  }
+  return r;
+}
+
+// nbody_rsqrt_selftest(): bit patterns first .. first+count-1, one per thread per round; out[0] = patterns where the nine-operation result
+// was accepted and differs from the IEEE form (must stay 0), out[1] = patterns sent to the IEEE form, out[2] = smallest offending pattern + 1
+__global__ void __launch_bounds__(256) rsqrt_selftest_kernel(unsigned first, unsigned long long count, unsigned long long* out) {
+  unsigned long long bad = 0, slow = 0, worst = ~0ull;
+  for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (unsigned long long)gridDim.x * blockDim.x) {
+    unsigned bits = first + (unsigned)k;
+    float x = __builtin_bit_cast(float, bits), r;
+    bool ok = rsqrt_fast_f32(x, r);
+    float s = rsqrt_ieee_f32(x);
+    if (!ok) { ++slow; continue; }
+    if (__builtin_bit_cast(unsigned, r) != __builtin_bit_cast(unsigned, s)) { ++bad; if ((unsigned long long)bits < worst) worst = bits; }
+  }
+  if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[2], worst); }
+  if (slow) atomicAdd(&out[1], slow);
+}
+// the strict 1/sqrt of an array, as the force kernels evaluate it (which = 0) or in the IEEE form alone (which = 1)
+__global__ void __launch_bounds__(256) rsqrt_array_kernel(const float* x, float* y, int n, int which) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float v = i < n ? x[i] : 1.0f;      // every lane stays in the wave-uniform branch
+  float r = which ? rsqrt_ieee_f32(v) : rsqrt_strict_f32(v);
+  if (i < n) y[i] = r;
+}
+
 template <int ARITH>
 __device__ __forceinline__ void pair_f32(float xj, float yj, float zj, float xi, float yi, float zi, float eps,
                                          float& ax, float& ay, float& az) {
@@ -152,7 +214,7 @@ __device__ __forceinline__ void pair_f32(float xj, float yj, float zj, float xi,
     d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, __builtin_fmaf(dz, dz, eps)));
   }
   float inv;
-  if constexpr (ARITH & kArithStrict) inv = (float)(1.0 / __builtin_sqrt((double)d2));
+  if constexpr (ARITH & kArithStrict) inv = rsqrt_strict_f32(d2);
   else inv = __builtin_amdgcn_rsqf(d2);            // v_rsq_f32, 1 ulp; d2 >= eps is never subnormal
   float inv2 = inv * inv;                          // S/cube.vhd:66-67
   float inv3 = inv * inv2;                         // S/cube.vhd:69-70

@@ -208,6 +208,24 @@ def comm_plan(form, rank, nranks, n):
     return [dict(zip(keys, buf[7 * k:7 * k + 7])) for k in range(cnt.value)]
 
 
+def rsqrt_selftest(first_bits=0, count=1 << 32):
+    """The strict 1/sqrt against its definition for `count` binary32 bit patterns from first_bits (default: every float), on the
+    device: (mismatches — must be 0, patterns evaluated by the IEEE form, smallest mismatching pattern)."""
+    bad, slow, first = C.c_ulonglong(), C.c_ulonglong(), C.c_uint()
+    L.check(L.load().nbody_rsqrt_selftest(int(first_bits), int(count), C.byref(bad), C.byref(slow), C.byref(first)))
+    return bad.value, slow.value, first.value
+
+
+def rsqrt_strict(x, ieee_only=False):
+    """y = the strict 1/sqrt of the float32 array x, as the force kernels evaluate it (or by the IEEE expression alone)."""
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    fp = C.POINTER(C.c_float)
+    L.check(L.load().nbody_rsqrt_strict(x.ctypes.data_as(fp), y.ctypes.data_as(fp), int(x.size), 1 if ieee_only else 0))
+    return y
+
+
 def unique_id():
     buf = C.create_string_buffer(128)
     L.check(L.load().nbody_unique_id(buf))
