@@ -152,10 +152,10 @@ int nbody_comm_selftest(long long *bytes_moved);
  * one-GPU box runs the P > 1 offsets, byte counts and pairing of the data path. */
 int nbody_comm_selftest_virtual(int vranks, int form, long long *bytes_moved);
 /* NBODY_ARITH_STRICT in binary32 evaluates 1/sqrt to the value (float)(1.0 / sqrt((double)x)) — IEEE square root and divide in binary64,
- * rounded once — from nine binary32 operations, and falls back to that expression itself for the ~2^-16 of arguments whose value lies too
+ * rounded once — from eight binary32 operations, and falls back to that expression itself for the ~2^-16 of arguments whose value lies too
  * close to a rounding boundary to be decided that way (csrc/nbody_kernels.hpp rsqrt_strict_f32).  nbody_rsqrt_selftest() proves it on the
  * device: for each of the `count` binary32 BIT PATTERNS first_bits, first_bits + 1, ... (count <= 2^32 covers every float) it evaluates both
- * and counts the patterns where the nine-operation value was accepted and differs (*mismatches: must be 0; *first_bad = the smallest such
+ * and counts the patterns where the eight-operation value was accepted and differs (*mismatches: must be 0; *first_bad = the smallest such
  * pattern) and the patterns sent to the IEEE form (*ieee_lanes).  Any pointer may be NULL.  Needs no context.
  * nbody_rsqrt_strict(): y[i] = that 1/sqrt of x[i], n values through host pointers, as the force kernels evaluate it (ieee_only = 0) or by
  * the IEEE expression alone (1) — the test surface that ties both to the CPU oracle. */

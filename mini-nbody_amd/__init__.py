@@ -12,6 +12,6 @@ from ._lib import (OPT_GRAPH, ARITH_FMA3, ARITH_REFERENCE, ARITH_REFERENCE_STRIC
                    OPT_WAVES_PER_SIMD, OPT_WSPLIT, OPT_XCD_MAP, SUM_BLOCKED, SUM_FPGA16, SUM_SEQ,
                    VARIANT_AUTO, VARIANT_ISA, VARIANT_LDS, VARIANT_READLANE, VARIANT_SMEM, NBodyError)
 from .bodies import make_bodies  # noqa: F401
-from .engine import NBody, comm_plan, unique_id  # noqa: F401
+from .engine import NBody, comm_plan, rsqrt_selftest, rsqrt_strict, unique_id  # noqa: F401
 
 __all__ = ["NBody", "NBodyError", "make_bodies", "unique_id", "bodies", "mailbox", "sharding"]

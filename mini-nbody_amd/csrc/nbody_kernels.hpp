@@ -142,13 +142,13 @@ constexpr int kArithRef = 1, kArithStrict = 2;
 // binary32.  About 150 issue cycles per wave.
 __device__ __forceinline__ float rsqrt_ieee_f32(float x) { return (float)(1.0 / __builtin_sqrt((double)x)); }
 
-// The same VALUE from nine binary32 operations for all but ~2^-16 of the arguments (round 4).  y = v_rsq_f32(x) is within 1 ulp, so the
+// The same VALUE from eight binary32 operations for all but ~2^-16 of the arguments (round 4).  y = v_rsq_f32(x) is within 1 ulp, so the
 // answer is y or a neighbour: with e = 1 - x y^2 (|e| < 2^-21), x^(-1/2) = y (1 - e)^(-1/2) = y + y e/2 + y 3e^2/8 + ..., and ONE fma
 // y + (y/2) e rounds the corrected value to binary32 correctly — provided e is known to ~2^-43, which binary32 delivers because the
 // product x y is carried as an exact pair (hi + lo = x y, an fma's error term) and 1 - hi y, - lo y are both tiny: each fma rounds at
 // <= 2^-46.  What is neglected (3e^2/8 <= 2^-44.4, the roundings of e, the oracle's own two binary64 roundings <= 2^-51.5) moves the
 // value by < 2^-43 y, which can only change the rounding if it lies that close to the midpoint of two binary32 neighbours.  That case is
-// DETECTED, not assumed away: the final fma is evaluated twice, with y/2 widened and narrowed by 2^-16 (a band of >= 2^-41 y about the
+// DETECTED, not assumed away: the final fma is evaluated twice, with the factor 1/2 widened and narrowed by 2^-16 (a band of >= 2^-41 y about the
 // correction where a midpoint can matter, 4x what is neglected even for a 2-ulp seed); rounding is monotone, so if both give the same
 // binary32 every value between them does, the oracle's included.  Where they differ (about 2^-16 of arguments; also every NaN, since a NaN
 // compares unequal to itself: x = inf, NaN or negative) the wave computes the IEEE form — one wave in ~1000 per source.  The seed's
@@ -162,21 +162,24 @@ __device__ __forceinline__ bool rsqrt_fast_f32(float x, float& r) {   // true: r
   float lo = __builtin_fmaf(x, y, -hi);
   float e = __builtin_fmaf(-hi, y, 1.0f);
   e = __builtin_fmaf(-lo, y, e);
-  r = __builtin_fmaf(y * (0.5f + kStrictBand), e, y);
-  float r2 = __builtin_fmaf(y * (0.5f - kStrictBand), e, y);
+  float t = y * e;                                    // rounded once more (2^-24 of the correction: far inside the band)
+  r = __builtin_fmaf(t, 0.5f + kStrictBand, y);
+  float r2 = __builtin_fmaf(t, 0.5f - kStrictBand, y);
   return r == r2;
 }
 __device__ __forceinline__ float rsqrt_strict_f32(float x) {
   float r;
   bool ok = rsqrt_fast_f32(x, r);
   if (__builtin_amdgcn_ballot_w64(!ok) != 0) {      // wave-uniform: no lane pays for the IEEE form unless one of the 64 needs it
-    float s = rsqrt_ieee_f32(x);
+    float xs = x;
+    asm volatile("" : "+v"(xs));                      // pins the IEEE form inside the branch: without it the compiler evaluates it
+    float s = rsqrt_ieee_f32(xs);                     // speculatively for every pair and selects (seen in force_lds_f32, force_readlane_f32)
     r = ok ? r : s;
   }
   return r;
 }
 
-// nbody_rsqrt_selftest(): bit patterns first .. first+count-1, one per thread per round; out[0] = patterns where the nine-operation result
+// nbody_rsqrt_selftest(): bit patterns first .. first+count-1, one per thread per round; out[0] = patterns where the eight-operation result
 // was accepted and differs from the IEEE form (must stay 0), out[1] = patterns sent to the IEEE form, out[2] = smallest offending pattern + 1
 __global__ void __launch_bounds__(256) rsqrt_selftest_kernel(unsigned first, unsigned long long count, unsigned long long* out) {
   unsigned long long bad = 0, slow = 0, worst = ~0ull;

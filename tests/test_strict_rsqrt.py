@@ -1,8 +1,8 @@
 """The strict 1/sqrt of the fp32 force kernels (NBODY_ARITH_STRICT): the VALUE is (float)(1.0 / sqrt((double)x)) — what the oracle computes
 (oracle/nbody_ref.c REF_RSQRT_F64; the reference's own rsqrt is a Xilinx IP instance, S/fxyz.vhd:101-102, whose rounding is unpinned) —
-but since round 4 it is obtained from nine binary32 operations on the v_rsq_f32 seed, with the IEEE expression only for arguments too
+but since round 4 it is obtained from eight binary32 operations on the v_rsq_f32 seed, with the IEEE expression only for arguments too
 close to a rounding boundary (csrc/nbody_kernels.hpp rsqrt_strict_f32).  Three statements are tied together here:
-  * a numpy model of the nine operations (CPU, seeds off by -2 ... +2 ulp): whatever it accepts equals the IEEE value;
+  * a numpy model of the eight operations (CPU, seeds off by -2 ... +2 ulp): whatever it accepts equals the IEEE value;
   * on the GPU, the kernel's evaluation against the IEEE expression for EVERY binary32 bit pattern (nbody_rsqrt_selftest);
   * on the GPU, both against numpy's binary64 sqrt and divide and against the oracle's ref_rsqrt.
 """
@@ -19,15 +19,16 @@ def fma32(a, b, c):
     return (a.astype(LD) * b.astype(LD) + c.astype(LD)).astype(np.float32)
 
 
-def nine_operations(x, y):
+def eight_operations(x, y):
     """rsqrt_fast_f32 of csrc/nbody_kernels.hpp, operation for operation; y is the seed.  Returns (value, accepted)."""
     one = np.ones_like(x)
     hi = x * y
     lo = fma32(x, y, -hi)
     e = fma32(-hi, y, one)
     e = fma32(-lo, y, e)
-    r1 = fma32(y * (np.float32(0.5) + BAND), e, y)
-    r2 = fma32(y * (np.float32(0.5) - BAND), e, y)
+    t = y * e
+    r1 = fma32(t, np.full_like(x, np.float32(0.5) + BAND), y)
+    r2 = fma32(t, np.full_like(x, np.float32(0.5) - BAND), y)
     return r1, r1 == r2
 
 
@@ -50,7 +51,7 @@ def test_model_accepts_only_the_ieee_value(ulps):
     seed = want.copy()
     for _ in range(abs(ulps)):
         seed = np.nextafter(seed, np.float32(np.inf if ulps > 0 else 0.0))
-    got, ok = nine_operations(x, seed)
+    got, ok = eight_operations(x, seed)
     assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
     rejected = 1.0 - ok.mean()
     print("seed off by %+d ulp: %.2e of the arguments go to the IEEE form" % (ulps, rejected))
@@ -66,19 +67,19 @@ def test_model_limits():
     x = arguments(100_000, 3)
     want = ieee(x)
     for factor in (1.5, 0.5, 1.0 + 2.0 ** -6):
-        got, ok = nine_operations(x, (want * np.float32(factor)).astype(np.float32))
+        got, ok = eight_operations(x, (want * np.float32(factor)).astype(np.float32))
         assert not ok.any(), factor
     with np.errstate(all="ignore"):
         for bad in (np.inf, np.nan):
-            got, ok = nine_operations(np.full(4, bad, np.float32), np.zeros(4, np.float32))
+            got, ok = eight_operations(np.full(4, bad, np.float32), np.zeros(4, np.float32))
             assert not ok.any()
-    got, ok = nine_operations(x, (want * np.float32(1.0 + 2.0 ** -12)).astype(np.float32))
+    got, ok = eight_operations(x, (want * np.float32(1.0 + 2.0 ** -12)).astype(np.float32))
     assert (ok & (got.view(np.uint32) != want.view(np.uint32))).any()      # the documented limit, kept visible
 
 
 @pytest.mark.gpu
-def test_every_binary32_bit_pattern():
-    from mini_nbody_amd.engine import rsqrt_selftest
+def test_every_binary32_bit_pattern(nb):
+    rsqrt_selftest = nb.rsqrt_selftest
     # positive normal numbers: the arguments a force kernel can produce (d2 >= 1e-9f)
     bad, slow, first = rsqrt_selftest(0x00800000, 0x7F800000 - 0x00800000)
     n = 0x7F800000 - 0x00800000
@@ -92,8 +93,8 @@ def test_every_binary32_bit_pattern():
 
 
 @pytest.mark.gpu
-def test_kernel_evaluation_equals_numpy_and_oracle():
-    from mini_nbody_amd.engine import rsqrt_strict
+def test_kernel_evaluation_equals_numpy_and_oracle(nb):
+    rsqrt_strict = nb.rsqrt_strict
     import oracle as O
     x = arguments(2_000_003, 11)
     x[:12] = np.array([1e-9, float.fromhex('0x1.12e0be826d695p-30'), 14.0, 56.0, 126.0, 224.0, 1.0, 0.1, 10.0, 4.0, 3.0, 2.0], np.float32)   # the testbench stimuli (tests/golden/kat_*.json)
@@ -110,3 +111,38 @@ def test_kernel_evaluation_equals_numpy_and_oracle():
     with np.errstate(all="ignore"):
         w = ieee(special)
     assert np.array_equal(a[~np.isnan(w)].view(np.uint32), w[~np.isnan(w)].view(np.uint32)) and np.isnan(a[np.isnan(w)]).all()
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(OBJDUMP), reason="needs ROCm's llvm-objdump")
+def test_ieee_form_stays_behind_its_branch_in_the_shipped_library(tmp_path):
+    """The point of the eight operations is lost if the compiler evaluates the IEEE form for every pair and selects (it did, in the LDS
+    and lane-broadcast kernels, until the branch body was pinned): in the code object of libnbody_hip.so every strict fp32 kernel
+    (one that holds both v_rsq_f32 and v_rsq_f64) must reach each v_rsq_f64 through a branch taken after the preceding v_rsq_f32."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = shutil.copy(os.path.join(root, "mini-nbody_amd", "libnbody_hip.so"), tmp_path)
+    subprocess.run([OBJDUMP, "--offloading", lib], cwd=tmp_path, check=True, capture_output=True)
+    obj = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(obj) == 1, os.listdir(tmp_path)
+    text = subprocess.run([OBJDUMP, "-d", os.path.join(tmp_path, obj[0])], check=True, capture_output=True, text=True).stdout
+    kernels = re.split(r"^[0-9a-f]+ <([^>]+)>:$", text, flags=re.M)
+    strict = 0
+    for name, body in zip(kernels[1::2], kernels[2::2]):
+        if "v_rsq_f32" not in body or "v_rsq_f64" not in body:
+            continue
+        strict += 1
+        branched = False
+        for line in body.splitlines():
+            if "v_rsq_f32" in line:
+                branched = False
+            elif "s_cbranch" in line:
+                branched = True
+            elif "v_rsq_f64" in line:
+                assert branched, name
+    assert strict >= 20, strict          # smem / lds / readlane / fpga16 kernels x STRICT, REFERENCE_STRICT (+ the two self-test kernels)
