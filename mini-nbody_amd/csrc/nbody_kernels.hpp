@@ -889,6 +889,24 @@ __global__ void __launch_bounds__(kBlock) force_readlane_f32(ForceArgs a) {
 // 16 (S/fxyz.vhd:129-145), latched rotated by (count mod 16) (S/fxyz.vhd:147-184)
 // and summed by the pairwise tree (S/final_adder.vhd:88-104).  One body per
 // lane; 48 accumulators live in VGPRs.  A study mode, not the timed path.
+// p[t] <- p[(t + rot) mod 16] for a wave-uniform rot, as a barrel shifter
+template <int B>
+__device__ __forceinline__ void rotate16_stage(float (&p)[16], bool on) {
+  if (on) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = p[(k + B) & 15];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] = t[k];
+  }
+}
+__device__ __forceinline__ void rotate16(float (&p)[16], int rot) {
+  rotate16_stage<8>(p, (rot & 8) != 0);
+  rotate16_stage<4>(p, (rot & 4) != 0);
+  rotate16_stage<2>(p, (rot & 2) != 0);
+  rotate16_stage<1>(p, (rot & 1) != 0);
+}
+
 template <int ARITH>
 __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
   int seg, jb, je, i;
@@ -902,11 +920,41 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
   for (int k = 0; k < 16; ++k) px[k] = py[k] = pz[k] = 0.0f;
   const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
   int j = jb;
-  for (; j + 16 <= je; j += 16) {
+  if constexpr (ARITH & kArithStrict) {
+    // Strict arithmetic: pair_f32 ends in a wave-uniform branch (rsqrt_strict_f32), which the compiler neither moves loads across nor
+    // keeps the accumulations in front of.  So the sources are loaded by hand, eight ahead (two s_load_dwordx16 in flight while the other
+    // eight are evaluated), and every partial sum is pinned where it is formed — left alone, all 48 fmas of an iteration sink behind the
+    // last branch and hold sixteen sources' differences and inverse cubes live (134 VGPRs, 3 waves per SIMD: 911 G pairs/s at N = 262144
+    // in the RTL-faithful mode; pinned: 71 VGPRs in this loop; profiles/r04_sweep_arith_n262144.txt).  Same operations in the same order.
+    auto eight = [&](const f4 (&p)[8], int h) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      f4 p = src[j + k];
-      pair_f32<ARITH>(p.x, p.y, p.z, me[0].x, me[0].y, me[0].z, eps, px[k], py[k], pz[k]);
+      for (int k = 0; k < 8; ++k) {
+        pair_f32<ARITH>(p[k].x, p[k].y, p[k].z, me[0].x, me[0].y, me[0].z, eps, px[h + k], py[h + k], pz[h + k]);
+        asm volatile("" : "+v"(px[h + k]), "+v"(py[h + k]), "+v"(pz[h + k]));
+      }
+    };
+    if (j + 16 <= je) {
+      f4 lo[8], hi[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) lo[k] = src[j + k];
+      for (; j + 16 <= je; j += 16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hi[k] = src[j + 8 + k];
+        eight(lo, 0);
+        if (j + 32 <= je) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) lo[k] = src[j + 16 + k];
+        }
+        eight(hi, 8);
+      }
+    }
+  } else {
+    for (; j + 16 <= je; j += 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        f4 p = src[j + k];
+        pair_f32<ARITH>(p.x, p.y, p.z, me[0].x, me[0].y, me[0].z, eps, px[k], py[k], pz[k]);
+      }
     }
   }
   const int tail = je - j;   // < 16
@@ -917,23 +965,21 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
       pair_f32<ARITH>(p.x, p.y, p.z, me[0].x, me[0].y, me[0].z, eps, px[k], py[k], pz[k]);
     }
   }
-  // results(t) = partial[(count + t) mod 16], zero where no item existed
+  // results(t) = partial[(count + t) mod 16], zero where no item existed.  count is the same for the whole wave, so the rotation is four
+  // wave-uniform stages of register moves (by 8, 4, 2, 1) on one axis at a time: 48 partial sums + 16 temporaries live, where selecting
+  // every result from all sixteen partials held 96 registers and set the kernel's occupancy (4 waves per SIMD instead of 7).
   const int count = je - jb;
   const int rot = count & 15;
-  float rx[16], ry[16], rz[16];
+  rotate16(px, rot); rotate16(py, rot); rotate16(pz, rot);
+  if (count < 16) {
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    float vx = 0.f, vy = 0.f, vz = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (((rot + t) & 15) == k) { vx = px[k]; vy = py[k]; vz = pz[k]; }
+    for (int t = 0; t < 16; ++t) {
+      if (count - 16 + t < 0) { px[t] = 0.f; py[t] = 0.f; pz[t] = 0.f; }
     }
-    if (count - 16 + t < 0) { vx = vy = vz = 0.f; }
-    rx[t] = vx; ry[t] = vy; rz[t] = vz;
   }
   Sums<float, 1> s;
   s.clear();
-  s.bx[0] = tree16(rx); s.by[0] = tree16(ry); s.bz[0] = tree16(rz);
+  s.bx[0] = tree16(px); s.by[0] = tree16(py); s.bz[0] = tree16(pz);
   finish_rows<float, f4, 1, 1>(seg, i, row_end, me, s, nullptr);
 }
 

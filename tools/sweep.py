@@ -2,7 +2,7 @@
 """Kernel configuration sweep on one GPU: (variant, bodies per lane, source sub-segments) -> G pairs/s from the
 HIP-event time of the force kernels.  One process, interleaved rounds (cdna guide §5.4 rule 24).
 usage: python tools/sweep.py [--n N] [--steps K] [--rounds M] [--configs "smem:4:1,lds:2:4,isa1:1:8:0:sum=seq:fuse=0,..."]
-config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked][:blk=K][:fuse=0|1][:long=0|1][:xcd=-1|0|1][:ws=1|4|16][:graph=K][:jsl=P (source slices, as a P-rank job cuts them)][:arith=fma3|reference|strict|refstrict]"""
+config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked|fpga16][:blk=K][:fuse=0|1][:long=0|1][:xcd=-1|0|1][:ws=1|4|16][:graph=K][:jsl=P (source slices, as a P-rank job cuts them)][:arith=fma3|reference|strict|refstrict]"""
 import argparse
 import importlib
 import os
@@ -47,7 +47,7 @@ def main():
         for c in cfgs:
             v, r, s, w, kv = c
             opts = dict(x.split("=") for x in kv)
-            eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_SEQ if opts.get("sum", "blocked") == "seq" else nb.SUM_BLOCKED)
+            eng.set_option(nb.OPT_SUM_ORDER, {"seq": nb.SUM_SEQ, "blocked": nb.SUM_BLOCKED, "fpga16": nb.SUM_FPGA16}[opts.get("sum", "blocked")])
             eng.set_option(nb.OPT_SUM_BLOCK, int(opts.get("blk", 1024)))
             eng.set_option(nb.OPT_FUSE_COMBINE, int(opts.get("fuse", -1)))
             eng.set_option(nb.OPT_ISA_LONG_BUFFERS, int(opts.get("long", -1)))
