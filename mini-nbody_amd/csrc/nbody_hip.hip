@@ -175,8 +175,8 @@ void resolve_config() {
   g.R = R;
   // The wave split (ForceArgs::wsplit) exists in the scalar-delivery kernels with one body per lane; the LDS and READLANE
   // deliveries stage sources for the whole workgroup and the FPGA order is a study of the reference's own tree.
-  const bool can_split = (g.variant == NBODY_VARIANT_ISA || g.variant == NBODY_VARIANT_SMEM) && R == 1 &&
-                         (g.fp64 || g.opt.sum_order != NBODY_SUM_FPGA16);
+  const bool fpga32 = !g.fp64 && g.opt.sum_order == NBODY_SUM_FPGA16;
+  const bool can_split = (g.variant == NBODY_VARIANT_ISA || g.variant == NBODY_VARIANT_SMEM) && R == 1;
   // automatic: wherever it exists, except for NBODY_SUM_SEQ in fp32, whose meaning is ONE sequential sum per segment (what a CPU
   // nbody.c does); fp64 contexts, which always sum sequentially and have 29 bits to spare, take the split
   const bool auto_split = g.fp64 || g.opt.sum_order != NBODY_SUM_SEQ;
@@ -188,6 +188,11 @@ void resolve_config() {
   // (one-rank contexts only: 8 virtual ranks of 8192 bodies each ran 2335 G pairs/s with 16 waves, 2553 with 4)
   const int auto_ws = (!g.fp64 && g.nslices == 1 && (n_local + 63) / 64 <= cus_ / 2) ? 16 : 4;
   g.wsplit = !can_split ? 1 : (g.opt.wsplit == 4 || g.opt.wsplit == 16) ? g.opt.wsplit : (g.opt.wsplit < 0 && auto_split) ? auto_ws : 1;
+  // The FPGA order's "split" is of another kind: its sixteen partial sums per row go to the sixteen waves of a workgroup
+  // (force_fpga16w_f32) — the same chains, rotation and tree, hence the same bits as one lane holding all sixteen (NBODY_OPT_WSPLIT 1,
+  // force_fpga16_f32), with sixteen times the waves: automatic, since the mode's home is N <= 32767 (the mailbox), where one wave per
+  // 64 rows leaves the chip empty
+  if (fpga32) g.wsplit = (can_split && g.opt.wsplit != 1) ? 16 : 1;
   if (g.wsplit == 16 && g.variant == NBODY_VARIANT_ISA && !g.fp64 && g.opt.isa_phase > 1) g.wsplit = 4;   // diagnostic loop forms: 4 waves
   // Small launches and large ones want different things (profiles/r02_small_n.md, one process, wall clock per step):
   //   large (even 64 segments give >= 16 workgroups per CU; N >= 16384 on one GPU): many short segments for load
@@ -496,6 +501,14 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
         return a.wsplit == 4 ? launch_timed(L, force_smem_f64<1, 4>, grid, a) : launch_timed(L, force_smem_f64<1, 1>, grid, a);
       case 2: return launch_timed(L, force_smem_f64<2, 1>, grid, a);
       default: return launch_timed(L, force_smem_f64<4, 1>, grid, a);
+    }
+  }
+  if (a.fpga16 && a.wsplit == 16) {
+    switch (g.opt.arith) {
+      case NBODY_ARITH_REFERENCE: return launch_timed(L, force_fpga16w_f32<1>, grid, a);
+      case NBODY_ARITH_STRICT: return launch_timed(L, force_fpga16w_f32<2>, grid, a);
+      case NBODY_ARITH_REFERENCE_STRICT: return launch_timed(L, force_fpga16w_f32<3>, grid, a);
+      default: return launch_timed(L, force_fpga16w_f32<0>, grid, a);
     }
   }
   if (a.fpga16) {

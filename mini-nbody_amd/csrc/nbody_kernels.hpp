@@ -423,11 +423,43 @@ __device__ __forceinline__ V4 load_word_sc1(__amdgpu_buffer_rsrc_t rs, int off) 
 // every other wave has left — and it is latency-bound: nseg / CF rounds of ~0.8 us (per-wave timestamps at N = 16384: all
 // source loops over at 62-63 us, the last arrivers done at 70.5 with 8 in flight; profiles/r02_small_n.md).  The kernel's
 // VGPR budget decides how many fit, 4 per partial in fp32 (hipcc splits a 12-byte load into dword loads in three passes).
-template <typename T, typename V4, int R, int WS, int CF = 0>
-__device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, const V4 (&me)[R], Sums<T, R>& s, V4 (*ws)[64]) {
+// results(T0) ... results(T0 + N - 1) of the FPGA order added as final_adder's tree adds them (leaves 2J, 2J+1 first; tree16 above is the
+// same association on an array): results(t) = partial[(count + t) mod 16], or zero where no item existed; partial 0 is the caller's own,
+// partial k > 0 is wave k's word in LDS.  Written as a recursion with the halves kept apart so that at most four words are in flight:
+// read all sixteen at once and the 64-VGPR budget of a 16-wave workgroup spills.
+template <int T0, int N>
+__device__ __forceinline__ f4 fpga_tree(f4 (*ws)[64], int lane, int count, const f4& own) {
+  if constexpr (N == 1) {
+    const int idx = (count + T0) & 15;                  // wave-uniform
+    f4 p = ws[idx > 0 ? idx - 1 : 0][lane];
+    if (idx == 0) p = own;
+    if (count - 16 + T0 < 0) { p.x = 0.f; p.y = 0.f; p.z = 0.f; }
+    return p;
+  } else {
+    f4 lo = fpga_tree<T0, N / 2>(ws, lane, count, own);
+    if constexpr (N >= 8) asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z) : : "memory");
+    const f4 hi = fpga_tree<T0 + N / 2, N / 2>(ws, lane, count, own);
+    f4 r = {lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, 0.f};
+    return r;
+  }
+}
+
+template <typename T, typename V4, int R, int WS, int CF = 0, int FPGA = 0>
+__device__ __forceinline__ void finish_rows(int seg, int lane_row, int row_end, const V4 (&me)[R], Sums<T, R>& s, V4 (*ws)[64], int fpga_count = 0) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
-  if constexpr (WS > 1) {
+  if constexpr (WS > 1 && FPGA) {
+    // force_fpga16w_f32: wave k holds partial sum k of the reference's sixteen (S/fxyz.vhd:129-145).  results(t) = partial[(count + t)
+    // mod 16], zero where no item existed (S/fxyz.vhd:147-184), then the adder tree (S/final_adder.vhd:88-104): the rotation is the
+    // order in which wave 0 reads the other waves' words (count is the same for the whole workgroup)
+    static_assert(R == 1 && WS == 16, "sixteen partial sums on sixteen waves");
+    if (wave > 0) { V4 o = {s.bx[0], s.by[0], s.bz[0], (T)0}; ws[wave - 1][lane] = o; }
+    __syncthreads();
+    if (wave > 0) return;
+    const f4 own = {s.bx[0], s.by[0], s.bz[0], 0.f};
+    const f4 sum = fpga_tree<0, 16>(ws, lane, fpga_count, own);
+    s.bx[0] = sum.x; s.by[0] = sum.y; s.bz[0] = sum.z;
+  } else if constexpr (WS > 1) {
     static_assert(R == 1, "the wave split is for one body per lane");
     if (wave > 0) { V4 o = {s.bx[0], s.by[0], s.bz[0], (T)0}; ws[wave - 1][lane] = o; }
     __syncthreads();
@@ -981,6 +1013,57 @@ __global__ void __launch_bounds__(kBlock) force_fpga16_f32(ForceArgs a) {
   s.clear();
   s.bx[0] = tree16(px); s.by[0] = tree16(py); s.bz[0] = tree16(pz);
   finish_rows<float, f4, 1, 1>(seg, i, row_end, me, s, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// The FPGA order with the sixteen partial sums of a row on sixteen WAVES (round 4; ForceArgs::wsplit = 16).  The reference's partial k
+// is the fma chain over the sources k, k + 16, k + 32, ... of the stream (S/fxyz.vhd:120-145: sixteen accumulations in flight): sixteen
+// independent chains.  force_fpga16_f32 keeps all sixteen in one lane, so a launch has one wave per 64 rows — at the mailbox's maximum
+// N = 32767 that is 512 waves on a chip with 8192 wave slots (2.56 ms per pass).  Here a workgroup of 16 waves owns 64 rows, wave k walks
+// the sources congruent to k with scalar delivery like every other kernel (one chain per lane, 8 sources loaded ahead), and wave 0 reads
+// the other fifteen sums from LDS in rotated order and adds the tree (finish_rows FPGA).  Same operations in the same order per chain,
+// same rotation, same tree: same bits as force_fpga16_f32 (tests: the rtl_n*.json fixtures, test_fpga16_order with NBODY_OPT_WSPLIT 1
+// and 16).
+template <int ARITH>
+__global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_f32(ForceArgs a) {
+  NB_WS_LDS(f4, 16);
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane_row = a.row0 + rb * 64 + (int)(threadIdx.x & 63);
+  const float eps = soft_f32();
+  const int row_end = a.row0 + a.row_count;
+  f4 me[1];
+  load_rows<float, f4, 1>(a, lane_row, row_end, me);
+  Sums<float, 1> s;
+  s.clear();
+  float px = 0.0f, py = 0.0f, pz = 0.0f;
+  const NB_CONST f4* src = (const NB_CONST f4*)(uintptr_t)a.src;
+  constexpr int G = 8;
+  int j = jb + wave;
+  if (j + 16 * (G - 1) < je) {
+    f4 cur[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) cur[k] = src[j + 16 * k];
+    for (; j + 16 * (2 * G - 1) < je; j += 16 * G) {
+      f4 nxt[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) nxt[k] = src[j + 16 * (G + k)];
+#pragma unroll
+      for (int k = 0; k < G; ++k) pair_f32<ARITH>(cur[k].x, cur[k].y, cur[k].z, me[0].x, me[0].y, me[0].z, eps, px, py, pz);
+#pragma unroll
+      for (int k = 0; k < G; ++k) cur[k] = nxt[k];
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) pair_f32<ARITH>(cur[k].x, cur[k].y, cur[k].z, me[0].x, me[0].y, me[0].z, eps, px, py, pz);
+    j += 16 * G;
+  }
+  for (; j < je; j += 16) {
+    f4 p = src[j];
+    pair_f32<ARITH>(p.x, p.y, p.z, me[0].x, me[0].y, me[0].z, eps, px, py, pz);
+  }
+  s.bx[0] = px; s.by[0] = py; s.bz[0] = pz;
+  finish_rows<float, f4, 1, 16, 0, 1>(seg, lane_row, row_end, me, s, ws_sums, je - jb);
 }
 
 // ---------------------------------------------------------------------------

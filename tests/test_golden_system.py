@@ -152,8 +152,9 @@ def test_oracle_reproduces_the_rtl_fixture(nb, oracle, oracle_fast, path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wsplit", [-1, 1], ids=["sixteen-waves", "one-lane"])
 @pytest.mark.parametrize("path", RTL_FIXTURES, ids=[os.path.basename(p) for p in RTL_FIXTURES])
-def test_engine_and_mailbox_reproduce_the_rtl_fixture(nb, path):
+def test_engine_and_mailbox_reproduce_the_rtl_fixture(nb, path, wsplit):
     """NBODY_ARITH_REFERENCE_STRICT + NBODY_SUM_FPGA16 + one segment — the three options INTEGRATION.md §1 lists as "RTL-faithful
     result" — through nbody_forces, through the reference's own RAM images (nbody_mailbox_run) and through the step loop:
     bit for bit the third statement's answer, no oracle in the loop"""
@@ -163,7 +164,8 @@ def test_engine_and_mailbox_reproduce_the_rtl_fixture(nb, path):
         eng.set_option(nb.OPT_ARITH, nb.ARITH_REFERENCE_STRICT)
         eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_FPGA16)
         eng.set_option(nb.OPT_JSUB, 1)
-        assert eng.config["nseg"] == 1 and eng.config["sum_order"] == "fpga16"
+        eng.set_option(nb.OPT_WSPLIT, wsplit)     # the sixteen partial sums on sixteen waves (automatic) or in one lane: same bits
+        assert eng.config["nseg"] == 1 and eng.config["sum_order"] == "fpga16" and eng.config["wsplit"] == (16 if wsplit < 0 else 1)
         assert np.array_equal(bits(eng.forces(fx["pos0"])), bits(fx["forces0"]))
         ram_a = nb.mailbox.encode_request(fx["pos0"])
         ram_b = nb.mailbox.run(eng, ram_a, clock_khz=300000)
