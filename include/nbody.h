@@ -76,10 +76,15 @@ enum {
                               sums are added through LDS in ascending source order (a third level of the sum, like the reference's
                               16 partial sums + adder tree, S/fxyz.vhd:129-145, S/final_adder.vhd:88-104).  Same number of waves and
                               walk per wave from a quarter / a sixteenth of the global partial sums.  1: a workgroup owns
-                              256 x IBLOCK bodies, every wave walks the whole segment (round 2's layout; the LDS / READLANE / FPGA16
+                              256 x IBLOCK bodies, every wave walks the whole segment (round 2's layout; the LDS / READLANE
                               kernels always).  -1 (default): where the kernel has it (SMEM and ISA deliveries, one body per lane),
                               16 when a rank owns <= 8192 bodies (fp32), else 4; 1 with NBODY_SUM_SEQ in fp32, which means ONE
-                              sequential sum per segment. */
+                              sequential sum per segment.
+                              With NBODY_SUM_FPGA16 (fp32) the split is of another kind and changes NO bit: -1 / 4 / 16 put the
+                              reference's sixteen partial sums of a body on the sixteen waves of a workgroup (wave k walks the
+                              sources k, k + 16, ... of the segment; wave 0 adds rotation and tree), 1 keeps all sixteen in one lane
+                              (rounds 1-3).  Sixteen times the waves: the mailbox's maximum N = 32767 takes 0.51 ms per pass
+                              instead of 2.56 (NBODY_INFO_WSPLIT then reports 16). */
   NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: which generated form of the hand-scheduled loop runs (tools/gen_force_loop.py).
                               1 = the product loop (default); 0 = the same instructions placed one 4-byte phase off (-27 %, kept
                               so that the placement effect can be re-measured).  fp64: 1 = the product loop (VALU instructions at

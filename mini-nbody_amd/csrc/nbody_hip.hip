@@ -174,7 +174,7 @@ void resolve_config() {
   if (g.opt.sum_order == NBODY_SUM_FPGA16 && !g.fp64) R = 1;
   g.R = R;
   // The wave split (ForceArgs::wsplit) exists in the scalar-delivery kernels with one body per lane; the LDS and READLANE
-  // deliveries stage sources for the whole workgroup and the FPGA order is a study of the reference's own tree.
+  // deliveries stage sources for the whole workgroup.  (The FPGA order has its own use of 16-wave workgroups, below.)
   const bool fpga32 = !g.fp64 && g.opt.sum_order == NBODY_SUM_FPGA16;
   const bool can_split = (g.variant == NBODY_VARIANT_ISA || g.variant == NBODY_VARIANT_SMEM) && R == 1;
   // automatic: wherever it exists, except for NBODY_SUM_SEQ in fp32, whose meaning is ONE sequential sum per segment (what a CPU

@@ -34,7 +34,8 @@
 // Who walks what (ForceArgs::wsplit, round 3): a workgroup owns 64 rows and its 4 or 16 waves walk one piece of the segment
 // each for those same rows; the piece sums are joined through LDS in ascending source order — a third level of the sum —
 // so the same waves need a quarter (a sixteenth) of the global partial sums.  wsplit = 1 is round 2's layout (256*R rows per
-// workgroup, every wave walks the whole segment), which the LDS, READLANE and FPGA-order kernels keep.
+// workgroup, every wave walks the whole segment), which the LDS and READLANE kernels keep.  In the FPGA order a 16-wave workgroup
+// means something else: wave k holds the reference's partial sum k of the workgroup's 64 rows (force_fpga16w_f32).
 //
 // How a row's force is finished (ForceArgs::finish): with one segment the kernel applies kick and drift itself;
 // with several, every 64-row unit stores its partial sums and the LAST to arrive for its rows (an agent-scope ticket
