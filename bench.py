@@ -47,6 +47,8 @@ Rank 0 prints ONE JSON line, always with:
   cpu_baseline  the oracle (oracle/nbody_ref.c, kind "port": the reference is VHDL and has no CPU path) timed on
                 this box's host cores, rank 0, after the timed region, on a bounded row sample — at N = 1; an N > 1 line
                 carries the object with value null (--cpu-baseline always times it there too).
+  strict_mode   (one GPU, fp32) the rate of NBODY_ARITH_STRICT — the arithmetic in which the GPU equals the CPU oracle bit for bit —
+                from up to 3 steps after the timed region: what the parity claim costs on this box; never `value`.
 and for N > 1: comm_exposed_ms_per_step — how long per step the compute stream sat waiting for arriving position slices
 (HIP events around every such wait; 0 = the transfers hid behind the own-slice kernel).
 """
@@ -554,6 +556,9 @@ def main(argv=None):
     ap.add_argument("--sum-block", type=int, default=0)
     ap.add_argument("--fuse", type=int, default=-1, help="1: one launch per step (in-launch combine), 0: two, -1: auto")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline never")
+    ap.add_argument("--strict-pass", choices=["auto", "never"], default="auto",
+                    help="auto: a one-GPU fp32 line also carries `strict_mode` — the rate of NBODY_ARITH_STRICT, the arithmetic that is "
+                         "bit-identical to the CPU oracle, from up to 3 steps AFTER the timed region (not the timed mode, not `value`)")
     ap.add_argument("--cpu-baseline", choices=["auto", "always", "never"], default="auto",
                     help="the oracle timed on this box's host cores after the timed region, rank 0: auto = at N = 1 only (the contract: a bounded "
                          "sample, N = 1 only — and at N > 1 the headline line is out 10-25 s sooner); always: also at N > 1")
@@ -807,6 +812,8 @@ def main(argv=None):
             out["comm_exposed_ms_per_step"] = round(wait_ms / max(1, kernel_steps), 4)
             out["comm_waits_per_step"] = round(waits / max(1, kernel_steps), 2)
             out["transport_used"] = "peer" if peer else ("rccl" if transport == "rccl" else "host")
+    if rank == 0 and world == 1 and not args.fp64 and args.strict_pass == "auto":
+        out["strict_mode"] = strict_pass(eng, nb, n, dt, args.steps)
     extras = want_forms or want_c5
     if eng is not None and not extras:
         eng.close()
@@ -840,6 +847,29 @@ def main(argv=None):
         barrier()
     if world > 1:
         dist.destroy_process_group()
+
+
+def strict_pass(eng, nb, n, dt, steps):
+    """What the parity claim costs, on the box that timed the headline: the same engine switched to NBODY_ARITH_STRICT — every operation
+    IEEE-exact, 1/sqrt = (float)(1.0 / sqrt((double)d2)): the arithmetic in which the GPU equals the CPU oracle bit for bit (tests -m gpu,
+    smoke()) — for up to 3 steps after the timed region.  Never the headline; a failure is reported in the object, not raised."""
+    try:
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        eng.set_option(nb.OPT_TIMING, 0)
+        eng.step(dt, 1)
+        eng.sync()
+        k = max(1, min(int(steps), 3))
+        t0 = time.perf_counter()
+        eng.step(dt, k)
+        eng.sync()
+        el = time.perf_counter() - t0
+        cfg = eng.config
+        return {"arith": "NBODY_ARITH_STRICT", "value": round(float(n) * float(n) * k / el / 1e9, 2), "unit": "billion pair-interactions/s",
+                "steps": k, "ms_per_step": round(1e3 * el / k, 3),
+                "kernel": {key: cfg[key] for key in ("variant", "nseg", "wsplit", "sum_order", "sum_block", "launches_per_step")},
+                "note": "bit-identical to the CPU oracle in this summation order (tests/test_gpu_parity.py); not the timed mode"}
+    except Exception as e:       # the headline is reported in any case
+        return {"arith": "NBODY_ARITH_STRICT", "value": None, "error": repr(e)}
 
 
 def comm_forms_pass(eng, nb, args, n, transport, run_timed, publish, steps=3):

@@ -1,0 +1,30 @@
+"""The one-GPU bench line end to end on the GPU box (a small size: the line's shape is what is checked, the headline is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_carries_roofline_cpu_baseline_and_strict_mode():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bodies", "65536", "--steps", "8", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 8 and j["dtype"] == "f32" and j["value"] > 1000 and j["config"]["finite"]
+    roof, cpu, strict = j["roofline"], j["cpu_baseline"], j["strict_mode"]
+    assert roof["bound"] == "valu" and 0.3 < roof["frac"] < 0.7 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+    # the bit-exact arithmetic on the same box, after the timed region: slower than the timed mode, far faster than rounds 1-3's 0.19 of it
+    assert strict["arith"] == "NBODY_ARITH_STRICT" and strict["kernel"]["variant"] == "smem"
+    assert 0.4 * j["value"] < strict["value"] < 0.9 * j["value"], (strict, j["value"])
+    # ... and switched off on request, and absent from an fp64 line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bodies", "16384", "--steps", "4", "--strict-pass", "never", "--cpu-baseline", "never"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "strict_mode" not in json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
