@@ -550,6 +550,12 @@ def test_fpga16_order(nb, oracle_fast, engine_factory, wsplit):
             got = eng.forces(pos)
             eng.set_option(nb.OPT_WSPLIT, 1)
             assert np.array_equal(bits(got), bits(eng.forces(pos))), n
+            # ... and cut as a 2-rank job cuts the sources (two slices x two segments, one launch per slice)
+            eng.set_option(nb.OPT_JSLICES, 2)
+            eng.set_option(nb.OPT_JSUB, 2)
+            one_lane = eng.forces(pos)
+            eng.set_option(nb.OPT_WSPLIT, wsplit)
+            assert eng.config["nseg"] == 4 and np.array_equal(bits(eng.forces(pos)), bits(one_lane)), n
 
 
 def test_bodyForce_integrate_config1_shape(nb, oracle_fast, engine_factory):
