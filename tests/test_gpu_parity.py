@@ -122,6 +122,48 @@ def test_random_configurations_strict_bit_exact(nb, oracle_fast, engine_factory)
         assert np.array_equal(bits(gp), bits(op)) and np.array_equal(bits(gv), bits(ov)), what
 
 
+def test_random_configurations_fpga_order(nb, oracle_fast, engine_factory):
+    """The same walk for the reference's own summation order (NBODY_SUM_FPGA16): size, pieces per slice, source slices, combine form, XCD
+    placement and all four arithmetics, 32 draws.  The sixteen partial sums on sixteen waves (automatic) and in one lane (NBODY_OPT_WSPLIT
+    1) are the same operations in the same order: forces, a window of rows and three steps of the device loop must agree bit for bit in
+    EVERY arithmetic, the timed one included; with one segment and strict arithmetic both equal the oracle's REF_SUM_FPGA16."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("NBODY_TEST_SEED", "20241004")) + 1)
+    for draw in range(int(os.environ.get("NBODY_TEST_DRAWS", "32"))):
+        n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 257, 1000, 1024, 1025, 2085, 4096, 5000])) if draw % 3 else int(rng.integers(1, 6001))
+        jsub, jsl = int(rng.choice([1, 1, 2, 3, 5])), int(rng.choice([1, 1, 2, 3]))      # explicit: the automatic count depends on the kernel's geometry
+        if n < jsl:
+            jsl = 1
+        fuse, xcd = int(rng.choice([1, 0])), int(rng.choice([0, 1]))
+        arith = int(rng.choice([nb.ARITH_FMA3, nb.ARITH_REFERENCE, nb.ARITH_STRICT, nb.ARITH_REFERENCE_STRICT]))
+        pos, vel = nb.make_bodies(n, seed=3000 + draw)
+        eng = engine_factory(n)
+        eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_FPGA16)
+        eng.set_option(nb.OPT_ARITH, arith)
+        eng.set_option(nb.OPT_JSUB, jsub)
+        eng.set_option(nb.OPT_JSLICES, jsl)
+        eng.set_option(nb.OPT_FUSE_COMBINE, fuse)
+        eng.set_option(nb.OPT_XCD_MAP, xcd)
+        got, nsegs = {}, {}
+        for ws in (-1, 1):
+            eng.set_option(nb.OPT_WSPLIT, ws)
+            what = (draw, n, jsub, jsl, fuse, xcd, arith, ws, eng.config)
+            nsegs[ws] = eng.config["nseg"]
+            assert eng.config["wsplit"] == (16 if ws < 0 else 1) and eng.config["sum_order"] == "fpga16", what
+            f = eng.forces(pos)
+            r0, cnt = (n // 3, max(1, min(200, n - n // 3)))
+            eng.upload(pos, vel)
+            assert np.array_equal(bits(eng.forces_rows(r0, cnt)), bits(f[r0:r0 + cnt])), what
+            eng.step(0.01, 3)
+            got[ws] = (f,) + tuple(eng.download())
+            if eng.config["nseg"] == 1 and arith in (nb.ARITH_STRICT, nb.ARITH_REFERENCE_STRICT):
+                d2 = O.D2_REFERENCE if arith == nb.ARITH_REFERENCE_STRICT else O.D2_FMA3
+                assert np.array_equal(bits(f), bits(oracle_fast.forces_f32(pos, d2=d2, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16))), what
+        assert nsegs[-1] == nsegs[1], what
+        for a, b in zip(got[-1], got[1]):
+            assert np.array_equal(bits(a), bits(b)), what
+
+
 def test_defaults_are_the_timed_configuration(nb, engine_factory):
     eng = engine_factory(1 << 16)
     cfg = eng.config
