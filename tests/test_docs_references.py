@@ -37,3 +37,20 @@ def test_cited_paths_exist():
             if not glob.glob(os.path.join(ROOT, tok)):
                 missing.append((doc, tok))
     assert not missing, missing
+
+
+def test_every_profile_of_the_current_round_is_indexed():
+    """... and the other way round for the evidence directory: every file of the newest round under profiles/ (and every pmc_*.json) has
+    its row in profiles/README.md (a `…_summary.txt` / `…_kernel_stats.csv` pair is indexed by its common stem)."""
+    index = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "*")))
+    rounds = sorted({m.group(1) for f in files for m in [re.match(r"(r\d\d)_", f)] if m})
+    newest = rounds[-1]
+    missing = []
+    for f in files:
+        if not (f.startswith(newest + "_") or f.startswith("pmc_")):
+            continue
+        stem = re.sub(r"_(summary\.txt|kernel_stats\.csv)$", "", f)      # r04_rocprofv3_fp32_n65536 is indexed as `r04_rocprofv3_fp32_n65536_*`
+        if not (f in index or stem in index or (f.startswith("pmc_") and "pmc_*.json" in index)):
+            missing.append(f)
+    assert not missing, missing
