@@ -556,6 +556,10 @@ def main(argv=None):
     ap.add_argument("--sum-block", type=int, default=0)
     ap.add_argument("--fuse", type=int, default=-1, help="1: one launch per step (in-launch combine), 0: two, -1: auto")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline never")
+    ap.add_argument("--arith", choices=["fma3", "reference", "strict", "refstrict", "rtl"], default="fma3",
+                    help="study runs only (the headline is fma3, the timed arithmetic): reference = the RTL's five roundings for d2; strict / "
+                         "refstrict = IEEE-exact, bit-identical to the CPU oracle; rtl = refstrict + the reference's 16 partial sums and adder "
+                         "tree over ONE stream of all N (the mailbox drop-in's arithmetic).  The line's metric and config say which")
     ap.add_argument("--strict-pass", choices=["auto", "never"], default="auto",
                     help="auto: a one-GPU fp32 line also carries `strict_mode` — the rate of NBODY_ARITH_STRICT, the arithmetic that is "
                          "bit-identical to the CPU oracle, from up to 3 steps AFTER the timed region (not the timed mode, not `value`)")
@@ -732,6 +736,12 @@ def main(argv=None):
         eng.set_option(nb.OPT_IBLOCK, args.iblock)
         eng.set_option(nb.OPT_JSUB, args.jsub)
         eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_BLOCKED if args.sum == "blocked" else nb.SUM_SEQ)
+        if args.arith != "fma3":
+            eng.set_option(nb.OPT_ARITH, {"reference": nb.ARITH_REFERENCE, "strict": nb.ARITH_STRICT, "refstrict": nb.ARITH_REFERENCE_STRICT,
+                                          "rtl": nb.ARITH_REFERENCE_STRICT}[args.arith])
+            if args.arith == "rtl":
+                eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_FPGA16)
+                eng.set_option(nb.OPT_JSUB, 1)
         if args.sum_block > 0:
             eng.set_option(nb.OPT_SUM_BLOCK, args.sum_block)
         eng.set_option(nb.OPT_FUSE_COMBINE, args.fuse)
@@ -776,7 +786,12 @@ def main(argv=None):
                    "sum_order": cfg["sum_order"], "sum_block": cfg["sum_block"], "launches_per_step": cfg["launches_per_step"],
                    "wsplit": cfg["wsplit"], "isa_phase": cfg["isa_phase"], "long_buffers": cfg["long_buffers"], "xcd_map": cfg["xcd_map"],
                    "kernel_source_sha": kernel_source_sha()}
+        if args.arith != "fma3":
+            run_cfg["arith"] = args.arith       # (absent = the timed arithmetic: the profiles of the headline keep matching)
         roof = roofline_of(eng, cfg, r, n, args.fp64, inline)
+        if args.arith != "fma3":
+            roof["note"] = ("study arithmetic %s, not the timed mode: the issue model beside it (30 cycles per wave-pair) is the timed arithmetic's; "
+                            "strict adds 8 full-rate operations and a compare per pair (DESIGN.md 3.6)" % args.arith)
         pj = matching_pmc(run_cfg)
         if pj:
             roof["traffic"] = pj.get("hbm_bytes_per_launch")
@@ -793,14 +808,15 @@ def main(argv=None):
                            "valu_issue_busy_formula": "(11 x 2 + 8 | 15 x 4 + 16 issue cycles per wave-pair) / measured SIMD cycles per wave-pair",
                            "sq_active_inst_valu_over_busy_cycles": pj.get("sq_valu_busy")}
         out = {
-            "metric": METRIC if (n == (1 << 20) and not args.fp64) else "billion pair-interactions/s at N=%d %s" % (n, "fp64" if args.fp64 else "fp32"),
+            "metric": METRIC if (n == (1 << 20) and not args.fp64 and args.arith == "fma3") else
+                      "billion pair-interactions/s at N=%d %s%s" % (n, "fp64" if args.fp64 else "fp32", "" if args.arith == "fma3" else " (--arith %s)" % args.arith),
             "value": round(value, 2), "unit": "billion pair-interactions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "N=%d %s all-pairs softened gravity, leapfrog kick-drift, dt=0.01, seed %d"
                                    % (n, "fp64" if args.fp64 else "fp32", args.seed),
                        "n_bodies": n, "pairs_per_step": pairs_per_step, "parallelism": "bodies sharded over %d GPU(s)" % world,
-                       "kernel": cfg, "kernel_source_sha": kernel_source_sha(),
+                       "kernel": cfg, "arith": args.arith, "kernel_source_sha": kernel_source_sha(),
                        "comm": ("%s / %s / overlap %d / stream priority %d%s" % ("hipMemcpyPeerAsync" if peer else COMM_NAMES.get(eng.info(nb._lib.INFO_COMM_FORM), "?"),
                                                                           transport, args.overlap, eng.info(nb._lib.INFO_COMM_PRIORITY),
                                                                           " / " + autotuned if autotuned else "")) if world > 1 else None,
@@ -812,7 +828,7 @@ def main(argv=None):
             out["comm_exposed_ms_per_step"] = round(wait_ms / max(1, kernel_steps), 4)
             out["comm_waits_per_step"] = round(waits / max(1, kernel_steps), 2)
             out["transport_used"] = "peer" if peer else ("rccl" if transport == "rccl" else "host")
-    if rank == 0 and world == 1 and not args.fp64 and args.strict_pass == "auto":
+    if rank == 0 and world == 1 and not args.fp64 and args.strict_pass == "auto" and args.arith == "fma3":
         out["strict_mode"] = strict_pass(eng, nb, n, dt, args.steps)
     extras = want_forms or want_c5
     if eng is not None and not extras:

@@ -66,6 +66,8 @@ def main():
                "nseg": k["nseg"], "sum_order": k["sum_order"], "sum_block": k["sum_block"], "launches_per_step": k["launches_per_step"],
                "wsplit": k.get("wsplit", 1), "isa_phase": k.get("isa_phase", 1), "long_buffers": k.get("long_buffers", -1), "xcd_map": k.get("xcd_map", -1),
                "kernel_source_sha": bench["config"].get("kernel_source_sha")}
+        if bench["config"].get("arith", "fma3") != "fma3":
+            cfg["arith"] = bench["config"]["arith"]        # bench.py --arith: a study run (absent = the timed arithmetic)
         wave_pairs = float(k["n_local"]) * bench["config"]["n_bodies"] / 64.0
         # The profiled run recorded its hash with the bench.py it carried.  Until round 4 that was a hash of the three kernel files whole;
         # now bench.kernel_source_sha() leaves the `#ifdef NBODY_DIAG_LOOPS` text out.  If the tree here still holds exactly the files that
