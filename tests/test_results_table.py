@@ -43,12 +43,14 @@ def test_scaling_record_with_extras(tmp_path):
                              "allgather": {"ms_per_step": 30.2, "comm_exposed_ms_per_step": 0.04, "value": 36400.0, "overlap": 1}},
               "config5": {"workload": "N=4194304 fp64 over 8 GPU(s), 2 timed steps", "value": 14900.0, "ms_per_step": 1180.0,
                           "roofline": {"frac": 0.474, "frac_of_issue_bound": 0.95}, "hbm_gb_per_s": 0.057, "hbm_frac_of_peak": 7.1e-6, "comm_exposed_ms_per_step": 0.1}}
-    scale = {"runs": [{"n": 1, "parsed": line(1, 4600.0)}, {"n": 2, "parsed": line(2, 9100.0)}, {"n": 4, "parsed": line(4, 18000.0)},
+    strict = {"strict_mode": {"arith": "NBODY_ARITH_STRICT", "value": 2844.0, "steps": 3, "ms_per_step": 386.6}}
+    scale = {"runs": [{"n": 1, "parsed": line(1, 4600.0, **strict)}, {"n": 2, "parsed": line(2, 9100.0)}, {"n": 4, "parsed": line(4, 18000.0)},
                       {"n": 8, "parsed": line(8, 35500.0, **extras), "tail": json.dumps(line(8, 35500.0)) + "\n"}]}
     json.dump(scale, open(tmp_path / "SCALE_r04.json", "w"))
     t = rt.table(str(tmp_path))
     rows = [r for r in t.splitlines() if r.startswith("| SCALE_r04.json")]
-    assert len(rows) == 4 + 3 + 1                                     # four headline lines (the raw copy of N = 8 de-duplicated), three forms, config 5
+    assert len(rows) == 4 + 1 + 3 + 1                                 # four headline lines (the raw copy of N = 8 de-duplicated), strict_mode, three forms, config 5
+    assert "| 1 | 2844 | 36.2 |" in t and "strict_mode: NBODY_ARITH_STRICT, bit-identical to the CPU oracle (3 steps" in t
     assert "| 8 | 35500 | 59.0 | 88.5 | 0.965 | 0.020 | rccl |" in t     # 35500 / (8 x 4600)
     assert "| 2 | 9100 | 59.0 | 88.5 | 0.989 |" in t
     assert "extras: NBODY_COMM_RING, overlap 2, 31.20 ms/step" in t and "| 1.250 |" in t
