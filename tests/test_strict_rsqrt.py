@@ -146,3 +146,21 @@ def test_ieee_form_stays_behind_its_branch_in_the_shipped_library(tmp_path):
             elif "v_rsq_f64" in line:
                 assert branched, name
     assert strict >= 20, strict          # smem / lds / readlane / fpga16 kernels x STRICT, REFERENCE_STRICT (+ the two self-test kernels)
+
+
+@pytest.mark.gpu
+def test_testbench_stimuli_through_the_kernels_evaluation(nb):
+    """The reference's own test inputs at this boundary — T/tb_sqrt.vhd:494, 503, 528-541: 1.0, the ramp 0.1 ... 10.0, seven special values
+    (tests/golden/kat_rsqrt.json; the testbench asserts only not-X, the outputs are the analytic values) — through the strict 1/sqrt as the
+    force kernels evaluate it: every finite case equals the fixture bit for bit (the fixture's 1-ulp allowance is for the fast v_rsq_f32),
+    NaN where the fixture says NaN.  The fast arithmetic's seed itself stays inside that allowance."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_rsqrt.json")))
+    x = np.array([int(c["a"], 16) for c in d["cases"]], np.uint32).view(np.float32)
+    got = nb.rsqrt_strict(x)
+    for c, g in zip(d["cases"], got):
+        if c["result"] == "nan":
+            assert np.isnan(g), c["label"]
+        else:
+            assert int(g.view(np.uint32)) == int(c["result"], 16), (c["label"], hex(int(g.view(np.uint32))), c["result"])
