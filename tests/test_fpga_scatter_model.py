@@ -136,3 +136,23 @@ def test_numeric_model_plus_tree_equals_the_oracle_fpga16_order(nb, oracle, n):
     got = np.array([oracle.tree16(axis[d]) for d in range(3)], np.float32)     # S/final_adder.vhd:88-104 on results(16 d ..)
     assert np.array_equal(got.view(np.uint32), want[0, :3].view(np.uint32)), n
     assert want[0, 3] == 0                                                      # S/compute_store.vhd:242
+
+
+@pytest.mark.parametrize("n", [1, 5, 15, 16, 17, 31, 40, 100, 257])
+def test_sixteen_waves_decomposition_equals_the_oracle_fpga16_order(nb, oracle, n):
+    """What force_fpga16w_f32 does (round 4), restated on the CPU: "wave" k runs ONE sequential fma chain from zero over the sources
+    k, k + 16, k + 32, ... (the oracle's plain sequential kernel on that subset), "wave 0" takes results(t) = chain[(n + t) mod 16] — zero
+    where n - 16 + t < 0 — and adds final_adder's tree.  Bit for bit the oracle's REF_SUM_FPGA16 over the whole stream, for every row:
+    the sixteen partial sums of the reference are independent chains, which is all the kernel relies on."""
+    pos, _ = nb.make_bodies(n, seed=70 + n)
+    for d2 in (O.D2_REFERENCE, O.D2_FMA3):
+        chains = np.zeros((16, n, 4), np.float32)
+        for k in range(min(16, n)):
+            chains[k] = oracle.forces_f32(pos, pos[k::16], d2=d2, rsqrt=O.RSQRT_F64, summ=O.SUM_SEQ)
+        got = np.zeros((n, 4), np.float32)
+        for i in range(n):
+            for axis in range(3):
+                leaves = np.array([chains[(n + t) % 16, i, axis] if n - 16 + t >= 0 else 0.0 for t in range(16)], np.float32)
+                got[i, axis] = oracle.tree16(leaves)
+        want = oracle.forces_f32(pos, d2=d2, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, d2)
