@@ -161,7 +161,9 @@ int nbody_comm_selftest_virtual(int vranks, int form, long long *bytes_moved);
  * close to a rounding boundary to be decided that way (csrc/nbody_kernels.hpp rsqrt_strict_f32).  nbody_rsqrt_selftest() proves it on the
  * device: for each of the `count` binary32 BIT PATTERNS first_bits, first_bits + 1, ... (count <= 2^32 covers every float) it evaluates both
  * and counts the patterns where the eight-operation value was accepted and differs (*mismatches: must be 0; *first_bad = the smallest such
- * pattern) and the patterns sent to the IEEE form (*ieee_lanes).  Any pointer may be NULL.  Needs no context.
+ * pattern) and the patterns sent to the IEEE form (*ieee_lanes).  Any pointer may be NULL.  Needs no context.  A host that relies on
+ * the strict arithmetic's bit-exactness runs it once per device over the positive normals (first_bits 0x00800000, count 0x7F000000:
+ * 10 ms) and refuses the mode unless *mismatches is 0 — build/nbody --strict / --rtl and the Python mirror do.
  * nbody_rsqrt_strict(): y[i] = that 1/sqrt of x[i], n values through host pointers, as the force kernels evaluate it (ieee_only = 0) or by
  * the IEEE expression alone (1) — the test surface that ties both to the CPU oracle. */
 int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned long long *mismatches, unsigned long long *ieee_lanes, unsigned *first_bad);

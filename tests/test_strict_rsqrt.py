@@ -164,3 +164,32 @@ def test_testbench_stimuli_through_the_kernels_evaluation(nb):
             assert np.isnan(g), c["label"]
         else:
             assert int(g.view(np.uint32)) == int(c["result"], 16), (c["label"], hex(int(g.view(np.uint32))), c["result"])
+
+
+def test_python_mirror_refuses_strict_arithmetic_on_a_device_that_fails_the_proof(nb, monkeypatch):
+    """engine.NBody.set_option runs the exhaustive device check the first time a process asks for fp32 strict arithmetic and refuses the
+    mode if one argument differs (the library's seed-accuracy contract is per device).  Stubbed here: no GPU needed."""
+    import importlib
+    eng_mod = importlib.import_module("mini-nbody_amd.engine")
+    calls = []
+
+    class Lib:
+        def nbody_set_option(self, k, v):
+            calls.append((k, v))
+            return 0
+
+    e = eng_mod.NBody.__new__(eng_mod.NBody)
+    e.fp64, e.lib = False, Lib()
+    monkeypatch.setattr(eng_mod, "_strict_rsqrt_checked", False)
+    monkeypatch.setattr(eng_mod, "rsqrt_selftest", lambda first, count: (3, 65024, 0x3F812345))
+    with pytest.raises(nb.NBodyError, match="refused"):
+        e.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+    assert calls == []                                            # the library was never asked
+    e.set_option(nb.OPT_ARITH, nb.ARITH_REFERENCE)                 # not a strict mode: no proof needed
+    monkeypatch.setattr(eng_mod, "rsqrt_selftest", lambda first, count: (0, 65024, 0))
+    e.set_option(nb.OPT_ARITH, nb.ARITH_REFERENCE_STRICT)
+    assert eng_mod._strict_rsqrt_checked and calls == [(nb.OPT_ARITH, nb.ARITH_REFERENCE), (nb.OPT_ARITH, nb.ARITH_REFERENCE_STRICT)]
+    e.fp64 = True                                                  # fp64 strict is IEEE sqrt and divide themselves
+    monkeypatch.setattr(eng_mod, "_strict_rsqrt_checked", False)
+    monkeypatch.setattr(eng_mod, "rsqrt_selftest", lambda first, count: (1, 0, 1))
+    e.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
