@@ -3,7 +3,7 @@
 HIPCC   ?= hipcc
 CC      ?= gcc
 ARCH    ?= gfx950
-PKG     := mini-nbody_amd
+PKG     := mini_nbody_amd
 CSRC    := $(PKG)/csrc
 # -ffp-contract=off: products are fused only where the source says fma (rounding points are part of the contract)
 # -fno-slp-vectorize: v_pk_*_f32 costs 4 cycles on gfx950 (profiles/r01_microbench_valu_issue.txt): no gain, more registers

@@ -54,7 +54,6 @@ and for N > 1: comm_exposed_ms_per_step — how long per step the compute stream
 """
 import argparse
 import glob
-import importlib
 import json
 import os
 import shutil
@@ -106,7 +105,7 @@ def cpu_baseline(n, seed, fp64):
     except (AttributeError, OSError):
         pass
     cores = ora.num_threads()
-    nb = importlib.import_module("mini-nbody_amd")
+    import mini_nbody_amd as nb
     pos, _ = nb.make_bodies(n, seed=seed, dtype=np.float64 if fp64 else np.float32)
 
     def run(rows):
@@ -142,7 +141,7 @@ def kernel_source_sha():
     h = hashlib.sha1()
     for f in ("nbody_kernels.hpp", "force_loop_gfx950.inc", "nbody_hip.hip"):
         skip = 0
-        for line in open(os.path.join(ROOT, "mini-nbody_amd", "csrc", f), "rb").read().splitlines(True):
+        for line in open(os.path.join(ROOT, "mini_nbody_amd", "csrc", f), "rb").read().splitlines(True):
             t = line.strip()
             if skip:
                 if t.startswith(b"#if"):
@@ -603,21 +602,21 @@ def main(argv=None):
     if code is not None:
         raise SystemExit(code)
 
-    if not os.path.exists(os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so")):
+    if not os.path.exists(os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so")):
         # fresh checkout (built files are git-ignored): build the HIP library; a failure is fatal, there is no fallback
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             subprocess.run(["make", "lib"], cwd=ROOT, check=True, capture_output=True)
         else:
             for _ in range(600):
-                if os.path.exists(os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so")):
+                if os.path.exists(os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so")):
                     break
                 time.sleep(0.5)
             time.sleep(2.0)
     import torch
     if os.environ.get(IMPORTED_ENV):
         open(os.environ[IMPORTED_ENV], "w").close()   # tells the supervisor: the image is paged in, what follows is the transport
-    nb = importlib.import_module("mini-nbody_amd")
-    D = importlib.import_module("mini-nbody_amd.distributed")
+    import mini_nbody_amd as nb
+    import mini_nbody_amd.distributed as D
 
     rank, world, local = D.env_rank()
     if world != args.gpus:

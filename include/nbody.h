@@ -2,7 +2,7 @@
  *
  * Plain C99: pointers, ints, floats.  No HIP, torch or C++ types cross this
  * boundary.  The library behind it is hand-written HIP for gfx950
- * (mini-nbody_amd/csrc/nbody_hip.hip); there is no CPU fallback: every entry
+ * (mini_nbody_amd/csrc/nbody_hip.hip); there is no CPU fallback: every entry
  * point fails with NBODY_ERR_NO_DEVICE when no GPU is usable.
  *
  * WHAT EACH ENTRY POINT REPLACES.  The reference (/root/reference, a VHDL FPGA
@@ -161,13 +161,19 @@ int nbody_comm_selftest_virtual(int vranks, int form, long long *bytes_moved);
  * close to a rounding boundary to be decided that way (csrc/nbody_kernels.hpp rsqrt_strict_f32).  nbody_rsqrt_selftest() proves it on the
  * device: for each of the `count` binary32 BIT PATTERNS first_bits, first_bits + 1, ... (count <= 2^32 covers every float) it evaluates both
  * and counts the patterns where the eight-operation value was accepted and differs (*mismatches: must be 0; *first_bad = the smallest such
- * pattern) and the patterns sent to the IEEE form (*ieee_lanes).  Any pointer may be NULL.  Needs no context.  A host that relies on
- * the strict arithmetic's bit-exactness runs it once per device over the positive normals (first_bits 0x00800000, count 0x7F000000:
- * 10 ms) and refuses the mode unless *mismatches is 0 — build/nbody --strict / --rtl and the Python mirror do.
+ * pattern) and the patterns sent to the IEEE form (*ieee_lanes).  Any pointer may be NULL.  Needs no context (it runs on the context's
+ * first device, or on the device a one-GPU context would take).
+ * nbody_strict_proof(): THE GATE.  That comparison over every positive normal binary32 (first_bits 0x00800000, count 0x7F000000: 10 ms),
+ * on EVERY device of the open context (without a context: on the device a one-GPU context would take), cached per device for the
+ * life of the process.  NBODY_OK: proved everywhere; NBODY_ERR_UNSUPPORTED: some device returned a different value (*mismatches,
+ * *first_bad — either may be NULL — say how many and where).  The library calls it itself: nbody_set_option(NBODY_OPT_ARITH, a strict
+ * mode) in an fp32 context and nbody_mailbox_open(., 1) answer NBODY_ERR_UNSUPPORTED and leave the arithmetic as it was unless every
+ * device of the context has proved it — no host layer has to remember the check.
  * nbody_rsqrt_strict(): y[i] = that 1/sqrt of x[i], n values through host pointers, as the force kernels evaluate it (ieee_only = 0) or by
  * the IEEE expression alone (1) — the test surface that ties both to the CPU oracle. */
 int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned long long *mismatches, unsigned long long *ieee_lanes, unsigned *first_bad);
 int nbody_rsqrt_strict(const float *x, float *y, int n, int ieee_only);
+int nbody_strict_proof(unsigned long long *mismatches, unsigned *first_bad);
 /* The transfer plan nbody_step() executes for rank `rank` of `nranks` over n bodies (form NBODY_COMM_RING or _DIRECT):
  * 7 values per send/receive pair {group, send_peer, send_first_word, send_words, recv_peer, recv_first_word, recv_words},
  * pairs of one group go into one ncclGroupStart/End.  Pure host arithmetic: needs no GPU and no context.  ops may be NULL
@@ -223,10 +229,32 @@ int nbody_forces_d(const double *pos_words, double *force_words, int n);
 int nbody_forces_rows(int first_row, int n_rows, float *force_words);
 int nbody_forces_rows_d(int first_row, int n_rows, double *force_words);
 
-/* The reference's mailbox, verbatim: ram_a = (N+1) 16-byte words, word 0 = control
- * {bit 0 BEGIN, bits 46:32 NUM_PTS}; ram_b = N words of forces.  On return word 0 of ram_a has
- * BEGIN = 0 and bits 63:32 = elapsed time in units of 1000 clocks of `clock_khz` (0: 300 MHz),
- * as S/top_level.vhd:121-146 counts them.  Returns NBODY_ERR_STATE if BEGIN is not set. */
+/* ---- the reference's mailbox, verbatim (its ONLY interface) ----
+ * RAM A = capacity + 1 words of 16 bytes: word 0 = control {bit 0 BEGIN, bits 46:32 NUM_PTS}, words 1..N = {x, y, z, ignored}
+ * (S/top_level.vhd:184-185, 206-208); RAM B = capacity words: word k-1 = {Fx, Fy, Fz, 0} of body k (S/compute_store.vhd:213, 242).
+ *
+ * nbody_mailbox_open(capacity, faithful): power-up of the PL block — ONE context that then serves any number of requests of any size.
+ *   capacity = body words of the two RAMs, 1..32767 (= ram_depth - 1, S/top_level.vhd:45); 0 means 32767.  Replaces any open context.
+ *   faithful = 1: the PL block's own bits — NBODY_ARITH_REFERENCE_STRICT (the RTL's rounding points, S/dxy.vhd:113-122, S/dzsoft.vhd:201-202,
+ *   S/dxyz_soft.vhd:149-150, 1/sqrt rounded once) + NBODY_SUM_FPGA16 (sixteen partial sums, rotation, adder tree: S/fxyz.vhd:129-184,
+ *   S/final_adder.vhd:88-104) + NBODY_OPT_JSUB 1 (one stream of all N sources per body, S/top_level.vhd:233-254) — granted only after the
+ *   device has proved the strict 1/sqrt (nbody_strict_proof; NBODY_ERR_UNSUPPORTED and no context otherwise).  faithful = 0: the
+ *   engine's timed arithmetic (every force within 1e-5 of the RTL's, not bit-equal).  nbody_shutdown() closes it.
+ * nbody_mailbox_rams(): the context's own RAM images — pinned host memory the device reads (RAM A) and writes (RAM B) directly, the PS's
+ *   view of the two block RAMs (S/top_level.vhd:100-117, 148-163).  A driver that fills *ram_a and passes these two pointers to
+ *   nbody_mailbox_run moves no byte on the host; any other host buffers are accepted too and cost one host copy each way.
+ *   *capacity (may be NULL) = the largest NUM_PTS the context takes.  Works in any one-GPU fp32 context (nbody_init(n, 1, 0, .): capacity n).
+ * nbody_mailbox_run(ram_a, ram_b, clock_khz): ONE request, synchronous (one request in flight, S/top_level.vhd:180-186).
+ *   NUM_PTS is sampled from word 0 with every request (S/top_level.vhd:180-186): any value 0..capacity, request after request, on the
+ *   same context.  Words >= NUM_PTS of RAM B are never written (S/compute_store.vhd:227-232); NUM_PTS = 0 completes at once with RAM B
+ *   untouched (S/top_level.vhd:189-192).  On return word 0 of ram_a is {ticks in bits 63:32, 0 elsewhere} — BEGIN reads 0 — with
+ *   ticks = 1 + elapsed time BEGIN-to-done in units of 1000 clocks of `clock_khz` (0: 300 MHz), as S/top_level.vhd:121-146, 255-263
+ *   count them.  Returns NBODY_ERR_STATE if BEGIN is not set (the FSM stays in `waiting`: nothing read, nothing written),
+ *   NBODY_ERR_ARG if NUM_PTS exceeds the capacity (the RTL has no such case: its RAM always holds 32767 bodies).
+ *   The context's N, options, uploaded state's size and step graph are as before on return (its position buffer is overwritten, as by
+ *   nbody_forces).  A context over several devices or ranks keeps its fixed N (NUM_PTS must equal it). */
+int nbody_mailbox_open(int capacity, int faithful);
+int nbody_mailbox_rams(void **ram_a, void **ram_b, int *capacity);
 int nbody_mailbox_run(void *ram_a, void *ram_b, int clock_khz);
 
 /* Multi-process transport without RCCL: call nbody_init_rank(..., uid128 = NULL), then register a function that

@@ -9,7 +9,7 @@
  *
  * The stream is SplitMix64 (counter-based: element k depends only on seed and
  * k), so C host code, the oracle and the numpy mirror in
- * mini-nbody_amd/bodies.py agree bit-for-bit and any shard of the bodies can be
+ * mini_nbody_amd/bodies.py agree bit-for-bit and any shard of the bodies can be
  * generated without generating the rest.  It does not depend on libc rand().
  *
  * Header-only C99; safe to include from C and C++.

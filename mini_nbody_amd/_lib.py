@@ -32,7 +32,7 @@ SYMBOLS = [
     "nbody_forces_d", "nbody_forces_rows", "nbody_mailbox_run", "nbody_kernel_time", "nbody_device_ptr",
     "nbody_set_host_gather", "nbody_download_slice", "nbody_comm_selftest", "nbody_forces_rows_d",
     "nbody_comm_selftest_virtual", "nbody_comm_plan", "nbody_comm_probe", "nbody_comm_time",
-    "nbody_rsqrt_selftest", "nbody_rsqrt_strict",
+    "nbody_rsqrt_selftest", "nbody_rsqrt_strict", "nbody_strict_proof", "nbody_mailbox_open", "nbody_mailbox_rams",
 ]
 
 
@@ -83,6 +83,8 @@ def load():
         "nbody_set_host_gather": [HOST_GATHER_FN, vp], "nbody_download_slice": [vp, vp],
         "nbody_rsqrt_selftest": [C.c_uint, C.c_ulonglong, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)],
         "nbody_rsqrt_strict": [fp, fp, i, i],
+        "nbody_strict_proof": [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)],
+        "nbody_mailbox_open": [i, i], "nbody_mailbox_rams": [C.POINTER(vp), C.POINTER(vp), C.POINTER(i)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

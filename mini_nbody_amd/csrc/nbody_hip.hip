@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "../../include/nbody.h"
@@ -95,6 +96,7 @@ struct Local {
   size_t partial_words = 0;            // capacity of `partial`
   unsigned* tickets = nullptr;         // arrival counters: one per wave of every block of 256 rows
   void* force = nullptr;
+  void* force_dst = nullptr;           // where a launch stores {Fx,Fy,Fz,0} instead of `force` (a mailbox request: RAM B itself)
   void* full_scratch = nullptr;        // N words: all-gather of a sharded array for the host (multi-process)
   int cur = 0;
   bool all_present = true;             // pos[cur] holds every slice
@@ -129,6 +131,11 @@ struct Global {
   float graph_dt = 0.f; double graph_dt64 = 0.0; int graph_cur = -1, graph_len = 0;
   bool init = false;
   int n = 0, fp64 = 0, tile = 256;
+  int cap = 0;                    // body words the buffers were allocated for (= the n of nbody_init; a mailbox request may bring fewer)
+  // the mailbox's two RAMs as the PS sees them (S/top_level.vhd:100-117, 148-163): pinned host memory the device reads (RAM A)
+  // and writes (RAM B) itself; allocated on the first request or by nbody_mailbox_open
+  void* mb_a = nullptr; void* mb_b = nullptr;
+  void* mb_a_dev = nullptr; void* mb_b_dev = nullptr;   // the same memory as the device addresses it
   int nranks = 1, nlocal = 0;
   bool multiprocess = false;
   Local loc[kMaxLocal];
@@ -229,7 +236,10 @@ void resolve_config() {
     const int mem_sub = (int)std::max(1LL, std::max(8LL, words_cap) / g.nslices);
     sub = std::min(sub, std::max(mem_sub, (target_blocks + blocks - 1) / blocks));
     sub = std::max(1, std::min(std::min(sub, 64), max_sub));
-    if (g.wsplit == 16) {
+    // (the FPGA order's sixteen waves are not a split of the segment: its segmentation stays what one lane per body resolves to, so
+    //  that NBODY_OPT_WSPLIT changes no bit there with NBODY_OPT_JSUB automatic either)
+    if (fpga32) {
+    } else if (g.wsplit == 16) {
       // 16-wave workgroups: about one workgroup per CU over the step's launches (N = 4096: 4 segments = 256 workgroups 9.7 us
       // per step, 2: 13.6, 8: 11.9; N = 2048: 4: 7.5, 2: 9.5; N = 8192: 2: 22.0, 4: 23.2, 1: 36.6), pieces of >= 32 sources
       const int blocks64 = (n_local + 63) / 64;
@@ -444,7 +454,7 @@ void fill_args(Local& L, ForceArgs& a, int row0, int row_count, const Finish& fi
   a.partial = L.partial;
   a.vel = L.vel;
   a.pos_next_rows = word_ptr(L.pos[L.cur ^ 1], (size_t)L.first);
-  a.force_out = fin.store_force ? L.force : nullptr;
+  a.force_out = fin.store_force ? (L.force_dst ? L.force_dst : L.force) : nullptr;
   a.tickets = L.tickets;
   a.n_src = g.n; a.n_rows = L.n_local; a.row0 = row0; a.row_count = row_count;
   a.nslices = g.nslices; a.sub = g.sub; a.nseg = g.nseg;
@@ -847,7 +857,7 @@ int init_common(int n, int fp64, int tile) {
   if (n <= 0 || n > (1 << 30)) return NBODY_ERR_ARG;
   if (tile == 0) tile = 256;
   if (tile < 64 || tile > 1024 || tile % 64) return NBODY_ERR_ARG;
-  g.n = n; g.fp64 = fp64 ? 1 : 0; g.tile = tile;
+  g.n = n; g.cap = n; g.fp64 = fp64 ? 1 : 0; g.tile = tile;
   g.steps_done = 0; g.stepped_eagerly = false;
   return NBODY_OK;
 }
@@ -1125,11 +1135,87 @@ int forces_rows_impl(int first_row, int n_rows, void* force_words) {
   return NBODY_OK;
 }
 
-// two HIP events that are destroyed on every way out
-struct EventPair {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+// ---- the reference's mailbox (S/top_level.vhd:176-272) ----
+// One context serves requests of ANY NUM_PTS up to its capacity, as the RTL samples NUM_PTS with every BEGIN (:180-186) against a RAM
+// sized once (:45).  The buffers are sized for the capacity; a request switches N and the launch configuration for its own duration
+// (resolve_config is host arithmetic) and leaves the context's N, state options and captured step graph as they were.
+constexpr int kMailboxMaxPoints = 32767;   // ram_depth - 1, S/top_level.vhd:45
+
+int mailbox_rams() {   // RAM A: capacity + 1 words, RAM B: capacity words (+ slack), pinned, mapped, coherent
+  if (g.mb_a && g.mb_b) return NBODY_OK;
+  Local& L = g.loc[0];
+  HIPC(hipSetDevice(L.device));
+  const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+  if (!g.mb_a) { HIPC(hipHostMalloc(&g.mb_a, ((size_t)g.cap + 1 + 64) * 16, flags)); memset(g.mb_a, 0, ((size_t)g.cap + 1 + 64) * 16); }
+  if (!g.mb_b) { HIPC(hipHostMalloc(&g.mb_b, ((size_t)g.cap + 64) * 16, flags)); memset(g.mb_b, 0, ((size_t)g.cap + 64) * 16); }
+  HIPC(hipHostGetDevicePointer(&g.mb_a_dev, g.mb_a, 0));
+  HIPC(hipHostGetDevicePointer(&g.mb_b_dev, g.mb_b, 0));
+  return NBODY_OK;
+}
+
+// N and the launch configuration of a one-rank context switched for the duration of one request
+struct ActiveN {
+  bool armed = false;
+  int n = 0, n_local = 0, variant = 0, R = 0, sub = 0, nslices = 0, nseg = 0, fuse = 0, wsplit = 0;
+  int enter(int n_new) {
+    Local& L = g.loc[0];
+    n = g.n; n_local = L.n_local; variant = g.variant; R = g.R; sub = g.sub; nslices = g.nslices; nseg = g.nseg; fuse = g.fuse; wsplit = g.wsplit;
+    armed = true;
+    g.n = n_new; L.n_local = n_new;
+    resolve_config();
+    NBC(ensure_partial(L));
+    if (g.tickets_dirty) {   // a failed launch sequence left arrival counters part-counted (they are zero between requests otherwise)
+      HIPC(hipMemsetAsync(L.tickets, 0, ((size_t)(g.cap + 63) / 64 + 32 + 63) / 64 * 64 * sizeof(unsigned), L.compute));
+      g.tickets_dirty = false;
+    }
+    return NBODY_OK;
+  }
+  ~ActiveN() {
+    if (!armed) return;
+    Local& L = g.loc[0];
+    g.n = n; L.n_local = n_local; g.variant = variant; g.R = R; g.sub = sub; g.nslices = nslices; g.nseg = nseg; g.fuse = fuse; g.wsplit = wsplit;
+  }
 };
+
+// completion of everything on `stream`: polled for the first 200 us (a request at the mailbox's sizes takes 7-500 us of device time and an
+// interrupt-driven wait adds tens of us of wake-up), then a blocking wait
+int wait_stream(hipStream_t stream) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    hipError_t e = hipStreamQuery(stream);
+    if (e == hipSuccess) return NBODY_OK;
+    if (e != hipErrorNotReady) { g_last_line = __LINE__; return (int)e; }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+  }
+  HIPC(hipStreamSynchronize(stream));
+  return NBODY_OK;
+}
+
+int mailbox_request(const void* ram_a, void* ram_b, int num_pts) {
+  Local& L = g.loc[0];
+  HIPC(hipSetDevice(L.device));
+  NBC(mailbox_rams());
+  ActiveN scope;
+  NBC(scope.enter(num_pts));
+  // RAM A: the library's own pinned image is read in place; any other host buffer is copied into it first
+  if (ram_a != g.mb_a) memcpy((char*)g.mb_a + 16, (const char*)ram_a + 16, (size_t)num_pts * 16);
+  // bodies are words 1..N                                              S/top_level.vhd:55, 206-208
+  hipLaunchKernelGGL(ingest_kernel, dim3((num_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, L.compute,
+                     (f4*)L.pos[L.cur], (const f4*)((const char*)g.mb_a_dev + 16), num_pts);
+  HIPC(hipGetLastError());
+  L.all_present = true;
+  // RAM B's write port: the force launch (or its combine) stores {Fx, Fy, Fz, 0} of body k at word k-1 itself, words >= N are never
+  // written                                                             S/compute_store.vhd:213, 227-242
+  const Finish fin = {false, false, true};
+  L.force_dst = g.mb_b_dev;
+  int rc = launch_force(L, 0, num_pts, g.nslices - 1, g.nslices, fin, 0.f, 0.0);
+  if (!rc) rc = launch_combine(L, 0, num_pts, fin, 0.f, 0.0);
+  L.force_dst = nullptr;
+  if (rc) { g.tickets_dirty = true; return rc; }
+  NBC(wait_stream(L.compute));
+  if (ram_b != g.mb_b) memcpy(ram_b, g.mb_b, (size_t)num_pts * 16);
+  return NBODY_OK;
+}
 
 }  // namespace
 
@@ -1440,10 +1526,7 @@ static int rsqrt_device() {
 }
 struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } };
 
-int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned long long* mismatches, unsigned long long* ieee_lanes, unsigned* first_bad) {
-  if (count == 0 || count > (1ull << 32) || (unsigned long long)first_bits + count > (1ull << 32)) return NBODY_ERR_ARG;
-  const int dev = rsqrt_device();
-  if (dev < 0) return NBODY_ERR_NO_DEVICE;
+static int rsqrt_selftest_on(int dev, unsigned first_bits, unsigned long long count, unsigned long long* res3) {
   HIPC(hipSetDevice(dev));
   DevBuf out;
   HIPC(hipMalloc(&out.p, 3 * sizeof(unsigned long long)));
@@ -1452,12 +1535,52 @@ int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned
   const unsigned long long wgs = (count + 255) / 256;
   rsqrt_selftest_kernel<<<dim3((unsigned)(wgs < 16384 ? wgs : 16384)), dim3(256)>>>(first_bits, count, (unsigned long long*)out.p);
   HIPC(hipGetLastError());
+  HIPC(hipMemcpy(res3, out.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return NBODY_OK;
+}
+
+int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned long long* mismatches, unsigned long long* ieee_lanes, unsigned* first_bad) {
+  if (count == 0 || count > (1ull << 32) || (unsigned long long)first_bits + count > (1ull << 32)) return NBODY_ERR_ARG;
+  const int dev = rsqrt_device();
+  if (dev < 0) return NBODY_ERR_NO_DEVICE;
   unsigned long long res[3];
-  HIPC(hipMemcpy(res, out.p, sizeof(res), hipMemcpyDeviceToHost));
+  NBC(rsqrt_selftest_on(dev, first_bits, count, res));
   if (mismatches) *mismatches = res[0];
   if (ieee_lanes) *ieee_lanes = res[1];
   if (first_bad) *first_bad = res[0] ? (unsigned)res[2] : 0u;
   return NBODY_OK;
+}
+
+// The proof the strict binary32 arithmetic rests on, per DEVICE and once per process: every positive normal binary32 through the
+// eight-operation 1/sqrt and through its IEEE definition on device `dev`, no accepted value differing (about 10 ms).  The library
+// runs it itself before it lets a context use NBODY_ARITH_STRICT / _REFERENCE_STRICT (nbody_set_option, nbody_mailbox_open): on
+// every device of the context, so that no host layer has to remember it.  NBODY_STRICT_PROOF_FAIL=1 makes it fail (the refusal's test).
+static int g_strict_proved[64] = {};   // 0 unknown, 1 proved, -1 refuted
+static unsigned long long g_strict_bad = 0; static unsigned g_strict_first_bad = 0;
+static int prove_strict_on(int dev) {
+  if (dev < 0 || dev >= 64) return NBODY_ERR_ARG;
+  if (g_strict_proved[dev] == 0) {
+    unsigned long long res[3];
+    NBC(rsqrt_selftest_on(dev, 0x00800000u, 0x7F800000ull - 0x00800000ull, res));
+    const char* fail = getenv("NBODY_STRICT_PROOF_FAIL");
+    if (fail && atoi(fail)) { res[0] = 1; res[2] = 0x00800000u; }
+    g_strict_proved[dev] = res[0] ? -1 : 1;
+    if (res[0]) { g_strict_bad = res[0]; g_strict_first_bad = (unsigned)res[2]; }
+  }
+  return g_strict_proved[dev] > 0 ? NBODY_OK : NBODY_ERR_UNSUPPORTED;
+}
+static int prove_strict_context() {
+  for (int l = 0; l < g.nlocal; ++l) NBC(prove_strict_on(g.loc[l].device));
+  return NBODY_OK;
+}
+
+int nbody_strict_proof(unsigned long long* mismatches, unsigned* first_bad) {
+  int rc;
+  if (g.init) rc = prove_strict_context();
+  else { const int dev = rsqrt_device(); if (dev < 0) return NBODY_ERR_NO_DEVICE; rc = prove_strict_on(dev); }
+  if (mismatches) *mismatches = rc == NBODY_ERR_UNSUPPORTED ? g_strict_bad : 0;
+  if (first_bad) *first_bad = rc == NBODY_ERR_UNSUPPORTED ? g_strict_first_bad : 0;
+  return rc;
 }
 
 int nbody_rsqrt_strict(const float* x, float* y, int n, int ieee_only) {
@@ -1479,6 +1602,8 @@ void nbody_shutdown(void) {
   drop_step_graph();
   for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);
   if (g.host_stage) { (void)hipHostFree(g.host_stage); g.host_stage = nullptr; }
+  if (g.mb_a) { (void)hipHostFree(g.mb_a); g.mb_a = nullptr; g.mb_a_dev = nullptr; }
+  if (g.mb_b) { (void)hipHostFree(g.mb_b); g.mb_b = nullptr; g.mb_b_dev = nullptr; }
   g.host_gather = nullptr; g.host_gather_user = nullptr;
   g.init = false; g.nlocal = 0; g.nranks = 1;
 }
@@ -1489,7 +1614,11 @@ int nbody_set_option(int key, int value) {
     case NBODY_OPT_IBLOCK: if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NBODY_ERR_ARG; g.opt.iblock = value; break;
     case NBODY_OPT_JSUB: if (value < 0 || value > 256) return NBODY_ERR_ARG; g.opt.jsub = value; break;
     case NBODY_OPT_JSLICES: if (value < 0 || value > kMaxRanks) return NBODY_ERR_ARG; g.opt.jslices = value; break;
-    case NBODY_OPT_ARITH: if (value < 0 || value > 3) return NBODY_ERR_ARG; g.opt.arith = value; break;
+    case NBODY_OPT_ARITH:
+      if (value < 0 || value > 3) return NBODY_ERR_ARG;
+      // the strict binary32 1/sqrt is used only on devices that have proved it (once per device and process, ~10 ms)
+      if ((value & 2) && g.init && !g.fp64) NBC(prove_strict_context());
+      g.opt.arith = value; break;
     case NBODY_OPT_SUM_ORDER: if (value < 0 || value > 2) return NBODY_ERR_ARG; g.opt.sum_order = value; break;
     case NBODY_OPT_SUM_BLOCK: if (value < 8 || value > (1 << 24) || value % 64) return NBODY_ERR_ARG; g.opt.sum_block = value; break;
     case NBODY_OPT_FUSE_COMBINE: if (value < -1 || value > 1) return NBODY_ERR_ARG; g.opt.fuse = value; break;
@@ -1561,7 +1690,7 @@ int nbody_get_info(int key, long long* value) {
 }
 
 const char* nbody_error_string(int code) {
-  static char buf[160];
+  static char buf[320];
   switch (code) {
     case NBODY_OK: return "ok";
     case NBODY_ERR_NOT_INIT: return "nbody: not initialised";
@@ -1569,7 +1698,13 @@ const char* nbody_error_string(int code) {
     case NBODY_ERR_NO_DEVICE: return "nbody: no usable HIP device (this library has no CPU path)";
     case NBODY_ERR_RCCL_LOAD: return "nbody: could not load librccl.so.1";
     case NBODY_ERR_STATE: return "nbody: wrong state for this call";
-    case NBODY_ERR_UNSUPPORTED: return "nbody: not supported in this configuration";
+    case NBODY_ERR_UNSUPPORTED:
+      if (g_strict_bad) {
+        snprintf(buf, sizeof(buf), "nbody: not supported in this configuration (strict arithmetic refused: the eight-operation 1/sqrt differs from "
+                 "(float)(1.0/sqrt((double)x)) for %llu arguments on a device, first 0x%08x)", g_strict_bad, g_strict_first_bad);
+        return buf;
+      }
+      return "nbody: not supported in this configuration";
     default: break;
   }
   if (code > 0 && code < 1000) { snprintf(buf, sizeof(buf), "HIP error %d (%s) near nbody_hip.hip:%d", code, hipGetErrorString((hipError_t)code), g_last_line); return buf; }
@@ -1611,28 +1746,58 @@ int nbody_forces_d(const double* pos_words, double* force_words, int n) { if (g.
 int nbody_forces_rows(int first_row, int n_rows, float* force_words) { if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
 int nbody_forces_rows_d(int first_row, int n_rows, double* force_words) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
 
+int nbody_mailbox_open(int capacity, int faithful) {
+  if (capacity == 0) capacity = kMailboxMaxPoints;
+  if (capacity < 1 || capacity > kMailboxMaxPoints) return NBODY_ERR_ARG;
+  NBC(nbody_init(capacity, 1, 0, 0));
+  int rc = mailbox_rams();
+  // the partial sums of the largest segmentation any request can resolve to (64 segments), so that no request allocates
+  if (!rc) { const int nseg = g.nseg; g.nseg = 64; rc = ensure_partial(g.loc[0]); g.nseg = nseg; }
+  if (!rc && faithful) {
+    // the PL block's own bits: its rounding points (S/dxy.vhd:113-122, S/dzsoft.vhd:201-202, S/dxyz_soft.vhd:149-150) with 1/sqrt rounded
+    // once — after this device has proved that 1/sqrt —, its sixteen partial sums, rotation and adder tree (S/fxyz.vhd:129-184,
+    // S/final_adder.vhd:88-104) over ONE stream of all N sources per body (S/top_level.vhd:233-254)
+    rc = nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_REFERENCE_STRICT);
+    if (!rc) rc = nbody_set_option(NBODY_OPT_SUM_ORDER, NBODY_SUM_FPGA16);
+    if (!rc) rc = nbody_set_option(NBODY_OPT_JSUB, 1);
+  }
+  if (rc) { nbody_shutdown(); return rc; }
+  return NBODY_OK;
+}
+
+int nbody_mailbox_rams(void** ram_a, void** ram_b, int* capacity) {
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (g.fp64 || g.nranks != 1) return NBODY_ERR_UNSUPPORTED;
+  NBC(mailbox_rams());
+  if (ram_a) *ram_a = g.mb_a;
+  if (ram_b) *ram_b = g.mb_b;
+  if (capacity) *capacity = g.cap < kMailboxMaxPoints ? g.cap : kMailboxMaxPoints;
+  return NBODY_OK;
+}
+
 int nbody_mailbox_run(void* ram_a, void* ram_b, int clock_khz) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (g.fp64 || !ram_a || !ram_b) return NBODY_ERR_ARG;
-  // word 0: bit 0 BEGIN, bits [46:32] NUM_PTS                         S/top_level.vhd:184-185
+  const auto t0 = std::chrono::steady_clock::now();
+  // word 0: bit 0 BEGIN, bits [46:32] NUM_PTS, sampled with every request        S/top_level.vhd:180-186
   uint32_t* w0 = (uint32_t*)ram_a;
-  if (!(w0[0] & 1u)) return NBODY_ERR_STATE;
+  if (!(w0[0] & 1u)) return NBODY_ERR_STATE;   // the FSM stays in `waiting`: nothing is read, nothing is written
   const int num_pts = (int)(w0[1] & 0x7FFFu);
-  if (num_pts != g.n) return NBODY_ERR_ARG;
-  EventPair ev;   // destroyed on every exit
-  HIPC(hipSetDevice(g.loc[0].device));
-  HIPC(hipEventCreate(&ev.e0)); HIPC(hipEventCreate(&ev.e1));
-  HIPC(hipEventRecord(ev.e0, g.loc[0].compute));
-  // bodies are words 1..N                                              S/top_level.vhd:55, 206-208
-  NBC(forces_impl((const float*)ram_a + 4, (float*)ram_b, num_pts));
-  HIPC(hipEventRecord(ev.e1, g.loc[0].compute));
-  HIPC(hipEventSynchronize(ev.e1));
-  float ms = 0.f;
-  HIPC(hipEventElapsedTime(&ms, ev.e0, ev.e1));
-  // completion: word 0 <- {ticks in [63:32], 0 elsewhere}: BEGIN reads 0  S/top_level.vhd:146, 255-263
-  // one tick = 1000 clocks (S/top_level.vhd:121-144); the counter starts at 1 on BEGIN's rising edge (:138-139)
+  if (g.nranks == 1) {
+    if (num_pts > g.cap) return NBODY_ERR_ARG;   // (the RTL's RAM always holds 32767 bodies; a smaller capacity is this library's notion)
+    // NUM_PTS = 0: block_setup finds THIS_PTR > NUM_PTS at once and goes to `complete` (S/top_level.vhd:189-192): RAM B untouched
+    if (num_pts > 0) NBC(mailbox_request(ram_a, ram_b, num_pts));
+  } else {
+    // a context over several devices / ranks keeps its fixed N: every rank brings the same images (nbody_forces)
+    if (num_pts != g.n) return NBODY_ERR_ARG;
+    NBC(forces_impl((const float*)ram_a + 4, (float*)ram_b, num_pts));
+  }
+  // completion: word 0 <- {ticks in [63:32], 0 elsewhere}: BEGIN reads 0          S/top_level.vhd:146, 255-263
+  // one tick = 1000 clocks (S/top_level.vhd:121-144); the counter goes to 1 on BEGIN's rising edge (:138-139); BEGIN-to-done as this
+  // host sees it (the device's reads of RAM A and writes of RAM B included)
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   const double khz = clock_khz > 0 ? (double)clock_khz : 300000.0;
-  uint32_t ticks = 1u + (uint32_t)((double)ms * khz / 1000.0);
+  const uint32_t ticks = 1u + (uint32_t)(ms * khz / 1000.0);
   w0[0] = 0; w0[1] = ticks; w0[2] = 0; w0[3] = 0;
   return NBODY_OK;
 }

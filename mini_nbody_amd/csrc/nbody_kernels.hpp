@@ -1179,6 +1179,14 @@ __global__ void __launch_bounds__(kBlock) combine_kernel(ForceArgs a) {
   apply_force<T, V4>(a, i, me, fx, fy, fz);
 }
 
+// The mailbox's RAM A read port (S/top_level.vhd:206-208, 238-240): body words 1..N of the host's RAM image — pinned host memory
+// the device reads over PCIe — into the resident source array, one 16-byte word per lane.  A kernel rather than a copy command:
+// it sits on the same queue as the force launch that follows, so a request is launches only, with no hand-over between engines.
+__global__ void __launch_bounds__(kBlock) ingest_kernel(f4* dst, const f4* ram_a_bodies, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) dst[i] = ram_a_bodies[i];
+}
+
 // integrate(): r += v * dt for the rank's bodies, in place.
 template <typename T, typename V4>
 __global__ void __launch_bounds__(kBlock) drift_kernel(V4* pos_rows, const V4* vel, int n_rows, float dt32, double dt64) {

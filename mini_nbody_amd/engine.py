@@ -33,8 +33,8 @@ class NBody:
 
     # ---- options / info ----
     def set_option(self, key, value):
-        if int(key) == L.OPT_ARITH and int(value) in (L.ARITH_STRICT, L.ARITH_REFERENCE_STRICT) and not self.fp64:
-            _check_strict_rsqrt_once()
+        """(A strict binary32 arithmetic is granted by the library only after every device of the context has proved its 1/sqrt —
+        nbody_strict_proof in include/nbody.h — and refused with ERR_UNSUPPORTED otherwise.)"""
         L.check(self.lib.nbody_set_option(int(key), int(value)))
 
     def info(self, key):
@@ -210,21 +210,15 @@ def comm_plan(form, rank, nranks, n):
     return [dict(zip(keys, buf[7 * k:7 * k + 7])) for k in range(cnt.value)]
 
 
-_strict_rsqrt_checked = False
-
-
-def _check_strict_rsqrt_once():
-    """The fp32 strict arithmetic's 1/sqrt rests on the accuracy of THIS device's v_rsq_f32 seed (csrc/nbody_kernels.hpp rsqrt_strict_f32):
-    the first time a context of this process asks for it, the device proves the equality with the IEEE definition for every positive
-    normal binary32 (about 10 ms) — and the mode is refused loudly if a single argument differs."""
-    global _strict_rsqrt_checked
-    if _strict_rsqrt_checked:
-        return
-    bad, _, first = rsqrt_selftest(0x00800000, 0x7F800000 - 0x00800000)
-    if bad:
-        raise L.NBodyError(L.ERR_UNSUPPORTED, "strict arithmetic refused: on this device the eight-operation 1/sqrt differs from "
-                           "(float)(1.0/sqrt((double)x)) for %d arguments (first: 0x%08x)" % (bad, first))
-    _strict_rsqrt_checked = True
+def strict_proof():
+    """The library's gate for the strict binary32 arithmetic (nbody_strict_proof): every positive normal binary32 through the
+    eight-operation 1/sqrt and through its IEEE definition on every device of the open context (else on the device a one-GPU context
+    would take), cached per device.  Returns (mismatches, first mismatching pattern) — (0, 0) when proved."""
+    bad, first = C.c_ulonglong(), C.c_uint()
+    rc = L.load().nbody_strict_proof(C.byref(bad), C.byref(first))
+    if rc not in (0, L.ERR_UNSUPPORTED):
+        L.check(rc)
+    return bad.value, first.value
 
 
 def rsqrt_selftest(first_bits=0, count=1 << 32):

@@ -53,12 +53,8 @@ int main(int argc, char **argv) {
   const float dt = 0.01f;
   const size_t words = (size_t)n * 4;
   CHECK(nbody_init(n, gpus, fp64, tile));
-  if ((strict || rtl) && !fp64) {
-    /* the strict 1/sqrt rests on this device's v_rsq_f32 seed: let the device prove it for every positive normal binary32 first (10 ms) */
-    unsigned long long bad = 0; unsigned first_bad = 0;
-    CHECK(nbody_rsqrt_selftest(0x00800000u, 0x7F800000ull - 0x00800000ull, &bad, NULL, &first_bad));
-    if (bad) { fprintf(stderr, "strict arithmetic refused: 1/sqrt differs from its IEEE definition for %llu arguments (first 0x%08x)\n", bad, first_bad); return 1; }
-  }
+  /* (a strict binary32 arithmetic is granted by the library only after every device of the context has proved the strict 1/sqrt for
+     every positive normal binary32 — nbody_strict_proof, 10 ms per device; otherwise the option call fails and CHECK reports why) */
   if (strict) CHECK(nbody_set_option(NBODY_OPT_ARITH, NBODY_ARITH_STRICT));   /* IEEE-exact: bit-identical to the CPU oracle */
   if (rtl) {
     /* the RTL-faithful result: the reference's own five roundings for d2 (S/dxy.vhd:113-122, S/dzsoft.vhd:201-202,

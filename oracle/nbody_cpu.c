@@ -2,7 +2,7 @@
  *
  * TEST INFRASTRUCTURE / CPU BASELINE, not product code: the reference tree has no nbody.c, so this is
  * the oracle (nbody_ref.c) behind the same command line, initial conditions, loop and report line as the GPU host
- * program mini-nbody_amd/host/nbody.c — which makes the two directly comparable (same checksum in --strict mode).
+ * program mini_nbody_amd/host/nbody.c — which makes the two directly comparable (same checksum in --strict mode).
  *
  * Summation order: --sum seq (default: what a plain CPU nbody.c does, one accumulator per body) or
  * --sum blocked [--block K] [--segments S] [--wsplit W]: the GPU engine's order (blocks of K sources, S source segments

@@ -2,7 +2,7 @@
  *
  * TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may link, load or call anything in oracle/.
- * The product path (mini-nbody_amd/, include/nbody.h) never routes through it.
+ * The product path (mini_nbody_amd/, include/nbody.h) never routes through it.
  *
  * What it restates: the arithmetic of the reference's FPGA force pipeline
  * (/root/reference/vec_add.srcs/sources_1/new/ (*.vhd), "S/" below), rounding
@@ -51,7 +51,7 @@ enum { REF_SUM_SEQ = 0,      /* one accumulator, sources in ascending order (S/t
                                 (S/fxyz.vhd:129-145, S/final_adder.vhd:88-104); this is the same remedy shaped for a SIMT
                                 lane (one fold per `block` sources instead of 16 live partials) */ };
 
-/* The engine's full summation order (mini-nbody_amd/csrc/nbody_kernels.hpp): the sources are cut into `nslices` balanced
+/* The engine's full summation order (mini_nbody_amd/csrc/nbody_kernels.hpp): the sources are cut into `nslices` balanced
  * slices (one per rank) of `sub` pieces each; every segment is summed on its own from zero (sum_mode, `block` sources per
  * block when sum_mode == REF_SUM_BLOCKED, counted from the segment's first source), and the segment sums are added in
  * ascending source order: F = ((p_0 + p_1) + p_2) + ...  nslices = sub = wsplit = 1 and REF_SUM_SEQ is the plain sequential sum. */

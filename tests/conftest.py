@@ -1,4 +1,3 @@
-import importlib
 import os
 import sys
 
@@ -18,14 +17,14 @@ def pytest_sessionstart(session):
     """Built artefacts are git-ignored; on a fresh checkout build them once (hipcc cross-compiles without a GPU).
     A failing build fails the session loudly: there is no fallback to test instead."""
     import subprocess
-    need = [os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"),
+    need = [os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"),
             os.path.join(ROOT, "oracle", "libnbody_ref.so"), os.path.join(ROOT, "oracle", "libnbody_ref_fast.so"),
-            os.path.join(ROOT, "oracle", "nbody_cpu"), os.path.join(ROOT, "mini-nbody_amd", "libnbody_hip_diag.so")]
+            os.path.join(ROOT, "oracle", "nbody_cpu"), os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip_diag.so")]
     # ... and again whenever a source is newer than what was built from it: a stale library must not be what the tests (or a gpurun
     # snapshot, which ships the built files) exercise
-    src = [os.path.join(ROOT, "mini-nbody_amd", "csrc", f) for f in ("nbody_hip.hip", "nbody_kernels.hpp", "force_loop_gfx950.inc")] + \
+    src = [os.path.join(ROOT, "mini_nbody_amd", "csrc", f) for f in ("nbody_hip.hip", "nbody_kernels.hpp", "force_loop_gfx950.inc")] + \
           [os.path.join(ROOT, "include", "nbody.h"), os.path.join(ROOT, "oracle", "nbody_ref.c"), os.path.join(ROOT, "oracle", "nbody_ref.h"),
-           os.path.join(ROOT, "oracle", "nbody_cpu.c"), os.path.join(ROOT, "mini-nbody_amd", "host", "nbody.c")]
+           os.path.join(ROOT, "oracle", "nbody_cpu.c"), os.path.join(ROOT, "mini_nbody_amd", "host", "nbody.c")]
     if all(os.path.exists(p) for p in need) and max(os.path.getmtime(p) for p in src) <= min(os.path.getmtime(p) for p in need):
         return
     r = subprocess.run(["make", "lib", "diag", "host", "oracle"], cwd=ROOT, capture_output=True, text=True)
@@ -49,8 +48,9 @@ def oracle_fast():
 
 @pytest.fixture(scope="session")
 def nb():
-    """The product package (directory name has a hyphen, hence importlib)."""
-    return importlib.import_module("mini-nbody_amd")
+    """The product package."""
+    import mini_nbody_amd
+    return mini_nbody_amd
 
 
 def has_gpu():

@@ -27,9 +27,8 @@ def f64_hex(x):
 
 
 def main(n=64, seed=21):
-    import importlib
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-    nb = importlib.import_module("mini-nbody_amd")
+    import mini_nbody_amd as nb
     import numpy as np
     p1, _ = nb.make_bodies(n, seed=seed, dtype=np.float64)
     p2, _ = nb.make_bodies(n, seed=seed + 1, dtype=np.float64)

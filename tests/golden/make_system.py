@@ -90,11 +90,10 @@ def splitmix64(state):
 def uniform_words(n, seed):
     """n bodies x {x,y,z,w} positions then velocities, as the repository's generator makes them (checked against it by
     tests/test_golden_system.py: the fixture's own input words are compared with make_bodies)"""
-    import importlib
     import sys
     root = os.path.dirname(os.path.dirname(HERE))
     sys.path.insert(0, root)
-    nb = importlib.import_module("mini-nbody_amd")
+    import mini_nbody_amd as nb
     pos, vel = nb.make_bodies(n, seed=seed)
     return [[float(v) for v in row] for row in pos], [[float(v) for v in row] for row in vel]
 

@@ -1,4 +1,4 @@
-"""mini-nbody_amd.distributed.autotune_comm on CPU: a world-size-2 gloo job with a stub engine whose steps take a time that
+"""mini_nbody_amd.distributed.autotune_comm on CPU: a world-size-2 gloo job with a stub engine whose steps take a time that
 depends on the transfer form AND the rank.  What must hold: the slowest rank's time decides, every rank makes the same choice
 (the forms are different RCCL call sequences — a disagreement would deadlock the real job), the library's default is kept unless
 another form is faster by more than the margin, ragged slice lengths drop the all-gather form, and the engine is left configured
@@ -15,11 +15,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
-    import importlib, json, os, sys, time
+    import json, os, sys, time
     sys.path.insert(0, {root!r})
     import torch.distributed as dist
-    nb = importlib.import_module("mini-nbody_amd")
-    D = importlib.import_module("mini-nbody_amd.distributed")
+    import mini_nbody_amd as nb
+    import mini_nbody_amd.distributed as D
     L = nb._lib
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -1,5 +1,5 @@
 """Every repository path the documents cite exists: DESIGN.md, BASELINE.md, README.md, INTEGRATION.md and profiles/README.md name
-their evidence by file (`profiles/...`, `tests/...`, `tools/...`, `mini-nbody_amd/...`, `oracle/...`, `include/...`); a stale name is
+their evidence by file (`profiles/...`, `tests/...`, `tools/...`, `mini_nbody_amd/...`, `oracle/...`, `include/...`); a stale name is
 a claim without its evidence."""
 import glob
 import os
@@ -7,9 +7,9 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOCS = ["DESIGN.md", "BASELINE.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")]
-PREFIXES = ("profiles/", "tests/", "tools/", "mini-nbody_amd/", "oracle/", "include/")
-BUILT = ("mini-nbody_amd/libnbody_hip.so", "mini-nbody_amd/libnbody_hip_diag.so", "oracle/libnbody_ref", "oracle/nbody_cpu", "oracle/_ref",
-         "mini-nbody_amd/csrc/microbench_streams.inc", "mini-nbody_amd/csrc/force_loop_mfma_gfx950.inc")     # made by `make`, git-ignored
+PREFIXES = ("profiles/", "tests/", "tools/", "mini_nbody_amd/", "oracle/", "include/")
+BUILT = ("mini_nbody_amd/libnbody_hip.so", "mini_nbody_amd/libnbody_hip_diag.so", "oracle/libnbody_ref", "oracle/nbody_cpu", "oracle/_ref",
+         "mini_nbody_amd/csrc/microbench_streams.inc", "mini_nbody_amd/csrc/force_loop_mfma_gfx950.inc")     # made by `make`, git-ignored
 
 
 def cited_paths(text, doc):

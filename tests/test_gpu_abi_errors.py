@@ -38,7 +38,7 @@ def test_error_codes_and_recovery(nb):
         assert lib.nbody_set_option(nb.OPT_VARIANT, 99) == L.ERR_ARG
         ram_a = np.zeros((129, 4), np.uint32)                      # BEGIN not set
         assert lib.nbody_mailbox_run(ram_a.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), 0) == L.ERR_STATE
-        ram_a[0, 0], ram_a[0, 1] = 1, 77                           # NUM_PTS != n of the context
+        ram_a[0, 0], ram_a[0, 1] = 1, 129                          # NUM_PTS beyond the context's capacity (its n)
         assert lib.nbody_mailbox_run(ram_a.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), 0) == L.ERR_ARG
         assert lib.nbody_set_host_gather(L.HOST_GATHER_FN(lambda *a: 0), None) == L.ERR_STATE   # not a multi-process context
         # still usable

@@ -1,4 +1,4 @@
-"""The C host program (mini-nbody_amd/host/nbody.c: plain C over the C-ABI) end to end on the GPU: its checksum of
+"""The C host program (mini_nbody_amd/host/nbody.c: plain C over the C-ABI) end to end on the GPU: its checksum of
 positions after 10 strict-mode iterations must equal the oracle's, for the host-pointer bodyForce()/integrate() loop
 and for the device-resident loop."""
 import os

@@ -1,0 +1,204 @@
+"""The reference's ONLY interface — the memory-mapped mailbox — as one long-lived context:
+NUM_PTS sampled with every BEGIN (S/top_level.vhd:180-186) against RAMs sized once (:45), N = 0 completing at once with RAM B
+untouched (:189-192), words >= N of RAM B never written (S/compute_store.vhd:227-232), word 0 rewritten with the tick count and
+BEGIN = 0 (S/top_level.vhd:146, 255-263).  All through the C-ABI (nbody_mailbox_open / _rams / _run)."""
+import ctypes as C
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SENTINEL = np.uint32(0xDEADBEEF)
+RTL = {json.load(open(f))["n"]: f for f in glob.glob(os.path.join(HERE, "golden", "rtl_*.json"))}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def fixture(n):
+    d = json.load(open(RTL[n]))
+    words = lambda key: np.array([int(x, 16) for x in d[key]], np.uint32).view(np.float32).reshape(-1, 4)   # noqa: E731
+    return words("pos0"), words("forces0")
+
+
+def rtl_oracle(ora, rows, src):
+    """the RTL's rounding points, 1/sqrt rounded once, sixteen partial sums + rotation + tree over ONE stream of all N"""
+    return ora.forces_f32(rows, src, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
+
+
+def test_one_context_serves_every_num_pts_bit_for_bit(nb, oracle_fast):
+    """ONE faithful context of the RTL's capacity replays rtl_n9 -> rtl_n100 -> rtl_n40 (exact-rational third statements of the RTL,
+    tests/golden/make_system.py) -> N = 32767 (row samples against the oracle) -> N = 0 -> rtl_n9 again, on the context's own RAMs
+    (no host copy) — every RAM B image bit for bit, and every word of RAM B from word N on left exactly as it was."""
+    big = nb.mailbox.MAX_POINTS
+    pos_big, _ = nb.make_bodies(big, seed=12)
+    with nb.Mailbox() as mb:                                   # capacity 32767 = ram_depth - 1, faithful
+        assert mb.capacity == big and mb.ram_a.shape == (big + 1, 4) and mb.ram_b.shape == (big, 4)
+        for n in (9, 100, 40, big, 0, 9):
+            mb.ram_b.view(np.uint32)[...] = SENTINEL
+            pos = pos_big if n == big else (np.zeros((0, 4), np.float32) if n == 0 else fixture(n)[0])
+            assert mb.post(pos) == n
+            out, ticks = mb.run(clock_khz=300000)
+            assert len(out) == n
+            ctl = nb.mailbox.decode_control(mb.ram_a)
+            assert ctl["begin"] == 0 and ctl["ticks"] == ticks >= 1                 # S/top_level.vhd:146, 255-263
+            assert np.all(mb.ram_a[0, [0, 2, 3]] == 0)                              # {ticks in 63:32, 0 elsewhere}
+            assert np.all(mb.ram_b.view(np.uint32)[n:] == SENTINEL), n             # S/compute_store.vhd:227-232
+            if n == 0:
+                assert ticks <= 2                                                   # straight to `complete`, S/top_level.vhd:189-192
+            elif n == big:
+                rows = np.r_[0:64, n // 2:n // 2 + 64, n - 64:n]
+                assert np.array_equal(bits(out[rows]), bits(rtl_oracle(oracle_fast, pos[rows], pos)))
+                assert np.all(out[:, 3] == 0)
+            else:
+                assert np.array_equal(bits(out), bits(fixture(n)[1])), n
+                assert np.all(out[:, 3] == 0)                                       # {Fx, Fy, Fz, 0}, S/compute_store.vhd:242
+
+
+def test_callers_own_ram_images(nb):
+    """Any host buffers do as RAM A / RAM B (one host copy each way): same bits, and the caller's RAM B beyond word N-1 is untouched."""
+    with nb.Mailbox(capacity=128) as mb:
+        ram_b = np.full((128, 4), SENTINEL, np.uint32).view(np.float32)
+        for n in (100, 9, 0, 40):
+            ram_b.view(np.uint32)[...] = SENTINEL
+            pos = fixture(n)[0] if n else np.zeros((0, 4), np.float32)
+            ram_a = nb.mailbox.encode_request(pos)
+            out = nb.mailbox.run(mb, ram_a, clock_khz=300000, ram_b=ram_b)
+            assert nb.mailbox.decode_control(ram_a)["begin"] == 0
+            assert np.all(ram_b.view(np.uint32)[n:] == SENTINEL)
+            if n:
+                assert np.array_equal(bits(out[:n]), bits(fixture(n)[1]))
+
+
+def test_requests_the_fsm_does_not_take(nb):
+    lib = nb._lib.load()
+    with nb.Mailbox(capacity=64) as mb:
+        # BEGIN not set: the FSM stays in `waiting` (S/top_level.vhd:180-186): nothing read, nothing written
+        mb.ram_b.view(np.uint32)[...] = SENTINEL
+        mb.post(fixture(9)[0])
+        mb.ram_a[0, 0] = 0
+        before = mb.ram_a.copy()
+        with pytest.raises(nb.NBodyError) as e:
+            mb.run()
+        assert e.value.code == nb._lib.ERR_STATE
+        assert np.array_equal(mb.ram_a, before) and np.all(mb.ram_b.view(np.uint32) == SENTINEL)
+        # NUM_PTS beyond this context's capacity (the RTL's RAM always holds 32767: the capacity is the library's notion)
+        mb.ram_a[0] = (1, 65, 0, 0)
+        with pytest.raises(nb.NBodyError) as e:
+            mb.run()
+        assert e.value.code == nb._lib.ERR_ARG and mb.ram_a[0, 0] == 1
+        # ... and the context still serves
+        assert np.array_equal(bits(mb.forces(fixture(40)[0])), bits(fixture(40)[1]))
+    assert lib.nbody_mailbox_open(40000, 1) == nb._lib.ERR_ARG                    # 15-bit NUM_PTS, S/top_level.vhd:45
+    assert lib.nbody_mailbox_open(-1, 1) == nb._lib.ERR_ARG
+    v = C.c_longlong()
+    assert lib.nbody_get_info(nb._lib.INFO_N, C.byref(v)) == nb._lib.ERR_NOT_INIT   # a refused open leaves no context
+
+
+def test_default_arithmetic_mailbox_is_within_tolerance(nb):
+    """faithful = 0: the engine's timed arithmetic (fma-contracted d2, v_rsq_f32, blocked sums) — within 1e-5 of the RTL's answer and
+    not equal to it, for every size in one context."""
+    with nb.Mailbox(capacity=4096, faithful=False) as mb:
+        for n in (100, 9, 40):
+            want = fixture(n)[1][:, :3].astype(np.float64)
+            got = mb.forces(fixture(n)[0])[:, :3].astype(np.float64)
+            d = np.abs(got - want).max() / np.abs(want).max()
+            assert 0 < d < 1e-5, (n, d)
+
+
+def test_requests_inside_an_nbody_init_context_leave_it_as_it_was(nb, oracle_fast):
+    """Any one-GPU fp32 context is a mailbox of capacity n.  A request of another size switches N for its own duration only: the
+    context's N, options and captured step graph survive, and after a fresh upload the step loop gives the bits it gave before."""
+    n = 1000
+    pos, vel = nb.make_bodies(n, seed=5)
+    small, _ = nb.make_bodies(300, seed=6)
+    with nb.NBody(n) as eng:
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        eng.upload(pos, vel)
+        eng.step(0.01, 8)
+        p0, v0 = eng.download()
+        order0, cfg0 = eng.order, eng.config
+        out = nb.mailbox.run(eng, nb.mailbox.encode_request(small))
+        assert eng.info(nb._lib.INFO_N) == n and eng.order == order0 and eng.config == cfg0
+        eng.upload(pos, vel)
+        eng.step(0.01, 8)
+        p1, v1 = eng.download()
+        assert np.array_equal(bits(p0), bits(p1)) and np.array_equal(bits(v0), bits(v1))
+    # the 300-body request itself: strict arithmetic in the order a 300-body context resolves to
+    with nb.NBody(300) as e300:
+        e300.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        want = oracle_fast.forces_order(small, None, order_=O.order(rsqrt=O.RSQRT_F64, **e300.order))
+    assert np.array_equal(bits(out), bits(want))
+
+
+def test_fpga_order_segmentation_does_not_depend_on_the_wave_split(nb):
+    """with NBODY_SUM_FPGA16 the sixteen waves are not a split of the segment, so with NBODY_OPT_JSUB automatic the
+    segmentation — hence every bit — is the same for NBODY_OPT_WSPLIT 1, -1 and 16."""
+    for n in (1000, 4096, 20000):
+        pos, _ = nb.make_bodies(n, seed=n)
+        with nb.NBody(n) as eng:
+            eng.set_option(nb.OPT_SUM_ORDER, nb.SUM_FPGA16)
+            got = {}
+            for ws in (1, -1, 16):
+                eng.set_option(nb.OPT_WSPLIT, ws)
+                got[ws] = (eng.config["nseg"], bits(eng.forces(pos)).copy())
+            assert got[1][0] == got[-1][0] == got[16][0], n
+            assert np.array_equal(got[1][1], got[-1][1]) and np.array_equal(got[1][1], got[16][1]), n
+
+
+PROOF_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+import mini_nbody_amd as nb
+L = nb._lib
+try:
+    nb.Mailbox(capacity=64, faithful=True)
+    print("mailbox: granted")
+except nb.NBodyError as e:
+    print("mailbox:", e.code, "refused" in str(e))
+import ctypes as C
+v = C.c_longlong()
+print("context after refusal:", L.load().nbody_get_info(L.INFO_N, C.byref(v)))
+with nb.NBody(64) as eng:
+    try:
+        eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
+        print("option: granted")
+    except nb.NBodyError as e:
+        print("option:", e.code)
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_REFERENCE)          # not a strict mode: no proof needed
+    print("proof:", nb.strict_proof())
+with nb.NBody(64, fp64=True) as eng:
+    eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)              # fp64 strict is IEEE sqrt and divide themselves
+    print("fp64 strict: granted")
+with nb.Mailbox(capacity=64, faithful=False) as mb:
+    print("plain mailbox: granted")
+"""
+
+
+def test_strict_arithmetic_is_refused_on_a_device_that_fails_the_proof(nb):
+    """The library itself gates the strict binary32 arithmetic on nbody_strict_proof (every positive normal binary32 on every device
+    of the context): a device that fails it — simulated with NBODY_STRICT_PROOF_FAIL=1 in a fresh process — gets NBODY_ERR_UNSUPPORTED
+    from nbody_set_option and from nbody_mailbox_open(., 1), which then leaves no context; everything that needs no proof still works."""
+    env = dict(os.environ, NBODY_STRICT_PROOF_FAIL="1")
+    p = subprocess.run([sys.executable, "-c", PROOF_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    assert lines[0] == "mailbox: %d True" % nb._lib.ERR_UNSUPPORTED, lines
+    assert lines[1] == "context after refusal: %d" % nb._lib.ERR_NOT_INIT, lines
+    assert lines[2] == "option: %d" % nb._lib.ERR_UNSUPPORTED, lines
+    assert lines[3].startswith("proof: (1,"), lines
+    assert lines[4:] == ["fp64 strict: granted", "plain mailbox: granted"], lines
+    # and on the real device the proof holds
+    assert nb.strict_proof() == (0, 0)

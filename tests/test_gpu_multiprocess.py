@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
-    import importlib, os, sys
+    import os, sys
     import numpy as np
     sys.path.insert(0, {root!r})
     import torch
-    nb = importlib.import_module("mini-nbody_amd")
-    D = importlib.import_module("mini-nbody_amd.distributed")
+    import mini_nbody_amd as nb
+    import mini_nbody_amd.distributed as D
     rank, world, local = D.init_process_group("gloo")
     n, steps = {n}, {steps}
     eng = D.make_engine(n, fp64={fp64}, transport={transport!r})

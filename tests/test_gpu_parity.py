@@ -335,15 +335,15 @@ def test_diagnostic_library_encodings_are_bit_identical(nb, tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "mini-nbody_amd", "libnbody_hip_diag.so")
+    lib = os.path.join(root, "mini_nbody_amd", "libnbody_hip_diag.so")
     if not os.path.exists(lib):
         pytest.fail("libnbody_hip_diag.so is missing: __graft_entry__.build() and tests/conftest.py both run `make diag`")
     script = tmp_path / "diag.py"
     script.write_text("""
-import importlib, sys
+import sys
 import numpy as np
 sys.path.insert(0, %r)
-nb = importlib.import_module("mini-nbody_amd")
+import mini_nbody_amd as nb
 n = 4096 + 37
 pos, _ = nb.make_bodies(n, seed=11)
 eng = nb.NBody(n)
@@ -417,7 +417,7 @@ def test_isa_loop_equals_compiled_kernel_ragged(nb, engine_factory, n, summ, lon
 
 def test_segmentation_matches_host_mirror_bitwise(nb, oracle_fast, engine_factory):
     """jslices x jsub segments combined in ascending order == the Python mirror of the decomposition
-    (mini-nbody_amd/sharding.py) driven by the oracle segment by segment, and == the oracle's own order function."""
+    (mini_nbody_amd/sharding.py) driven by the oracle segment by segment, and == the oracle's own order function."""
     n = 5000
     pos, _ = nb.make_bodies(n, seed=3)
     eng = engine_factory(n)

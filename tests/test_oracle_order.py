@@ -1,6 +1,6 @@
 """The oracle's statement of the engine's summation order (REF_SUM_BLOCKED, ref_order_t in oracle/nbody_ref.h):
 checked on CPU against an independent numpy emulation built from the plain sequential kernel, against the Python
-mirror of the segmentation (mini-nbody_amd/sharding.py), and for what it is for — the error against fp64."""
+mirror of the segmentation (mini_nbody_amd/sharding.py), and for what it is for — the error against fp64."""
 import numpy as np
 import pytest
 

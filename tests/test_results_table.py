@@ -93,7 +93,7 @@ def test_kernel_source_sha_ignores_the_diagnostic_build(tmp_path, monkeypatch):
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    d = tmp_path / "mini-nbody_amd" / "csrc"
+    d = tmp_path / "mini_nbody_amd" / "csrc"
     d.mkdir(parents=True)
     base = {"nbody_kernels.hpp": "int a;\n#ifdef NBODY_DIAG_LOOPS\nint diag1;\n#if X\nint nested;\n#endif\n#endif\nint b;\n",
             "force_loop_gfx950.inc": "#define P 1\n#ifdef NBODY_DIAG_LOOPS\n#define V19 2\n#endif  // NBODY_DIAG_LOOPS\n",

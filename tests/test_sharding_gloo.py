@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: world_size-2 (and 3) gloo jobs run the host-side decomposition
-(mini-nbody_amd/sharding.py — slices, ring exchange, ascending combine, kick, drift) with the oracle as
+(mini_nbody_amd/sharding.py — slices, ring exchange, ascending combine, kick, drift) with the oracle as
 the per-segment force function (tests may; the product's force function is the HIP kernel) and real
 torch.distributed send/recv for the ring, and must reproduce the single-process result bit for bit."""
 import os
@@ -14,12 +14,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
-    import importlib, os, sys
+    import os, sys
     import numpy as np
     import torch, torch.distributed as dist
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
     import oracle as O
-    nb = importlib.import_module("mini-nbody_amd")
+    import mini_nbody_amd as nb
     S = nb.sharding
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -5,7 +5,6 @@ alone, enqueued just before an N-body force pass on the compute stream, and just
 device's highest priority and at default priority (NBODY_COMM_PRIORITY=0, a second process).
 usage: python tools/comm_probe.py [--n N] [--reps R]      -> markdown table on stdout"""
 import argparse
-import importlib
 import os
 import subprocess
 import sys
@@ -15,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 
 def measure(n, reps, sizes):
-    nb = importlib.import_module("mini-nbody_amd")
+    import mini_nbody_amd as nb
     eng = nb.NBody(n, rank=0, nranks=1, uid=nb.unique_id())
     pos, vel = nb.make_bodies(n)
     eng.upload(pos, vel)

@@ -7,7 +7,6 @@ Row-sampled above N = 65536 (all N sources, `--rows` bodies in windows spread ov
 max-norm (largest component error over the sample / largest force component of the sample) and the worst row
 (|dF_i| / |F_i|).  Uses the oracle as the checker (tools are not product code); GPU lines need a GPU.
 usage: python tools/error_budget.py [--rows R] [--no-gpu] [N ...]"""
-import importlib
 import os
 import sys
 
@@ -33,7 +32,7 @@ def windows(n, rows):
 
 def main():
     import oracle as O
-    nb = importlib.import_module("mini-nbody_amd")
+    import mini_nbody_amd as nb
     ora = O.Oracle(fast=True)
     args = sys.argv[1:]
     rows = 2048

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate mini-nbody_amd/csrc/force_loop_gfx950.inc — the hand-scheduled inner loop of the fp32 force kernel.
+"""Generate mini_nbody_amd/csrc/force_loop_gfx950.inc — the hand-scheduled inner loop of the fp32 force kernel.
 
 Why the hot loop is written in ISA (measurements: profiles/r01_microbench_streams.txt via tools/gen_streams.py,
 profiles/r01_sweep_isa.txt):
@@ -48,7 +48,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "mini-nbody_amd", "csrc", "force_loop_gfx950.inc")
+OUT = os.path.join(ROOT, "mini_nbody_amd", "csrc", "force_loop_gfx950.inc")
 
 U = 22                                  # inv^2 (even)
 T2 = [20, 24]                           # d2 / inv / inv3 (even), alternating with the body index

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate mini-nbody_amd/csrc/force_loop_mfma_gfx950.inc — the fp32 force loop whose three coordinate differences per
+"""Generate mini_nbody_amd/csrc/force_loop_mfma_gfx950.inc — the fp32 force loop whose three coordinate differences per
 pair are produced by the matrix pipe.
 
 Why.  The force loop is VALU-issue-bound: 11 full-rate instructions + v_rsq_f32 per pair (tools/gen_force_loop.py,
@@ -29,7 +29,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "mini-nbody_amd", "csrc", "force_loop_mfma_gfx950.inc")
+OUT = os.path.join(ROOT, "mini_nbody_amd", "csrc", "force_loop_mfma_gfx950.inc")
 
 SOFT_BITS = 0x3089705F          # S/dzsoft.vhd:177
 T = {0: 21, 1: 20}              # d2 / inv / inv3 of pair r: parity opposite to r's

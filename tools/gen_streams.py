@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate instruction streams for the issue-rate microbenchmark (mini-nbody_amd/csrc/microbench_streams.inc).
+"""Generate instruction streams for the issue-rate microbenchmark (mini_nbody_amd/csrc/microbench_streams.inc).
 
 Each stream is one inline-asm block with explicit physical VGPRs (so that register banks and instruction order are
 exactly what is written here) and a count of the instructions in it.  The streams answer:
@@ -12,7 +12,7 @@ Run: python tools/gen_streams.py   (the output file is committed)
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "mini-nbody_amd", "csrc", "microbench_streams.inc")
+OUT = os.path.join(ROOT, "mini_nbody_amd", "csrc", "microbench_streams.inc")
 
 streams = []   # (name, description, [instr], n_instr, clobbers)
 

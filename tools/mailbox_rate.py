@@ -1,46 +1,73 @@
 #!/usr/bin/env python3
-"""What one request through the reference's mailbox costs on the GPU (nbody_mailbox_run: RAM A image in host memory -> RAM B image in
-host memory, S/top_level.vhd:184-263), per size and arithmetic: wall time per call (host copies included: the boundary hands over host
-buffers), and beside it what the RTL itself would take — N + ~250 clocks per 12 bodies (S/top_level.vhd:187-254)
-at the 300 MHz the testbenches' tick counter assumes.
-usage (on the GPU box): python tools/mailbox_rate.py [--calls 20]"""
+"""What one request through the reference's mailbox costs on the GPU (nbody_mailbox_run, S/top_level.vhd:184-263), per size and
+arithmetic, in ONE context of the RTL's capacity that serves every size in turn (NUM_PTS sampled with every BEGIN):
+  own RAMs     the context's pinned RAM A / RAM B (nbody_mailbox_rams): the device reads and writes them itself, no host copy;
+               the time of the C call alone (BEGIN raised -> word 0 rewritten)
+  any buffers  the caller's own (pageable) images: one host copy each way inside the call
+and beside it what the RTL itself would take — N + ~250 clocks per 12 bodies (S/top_level.vhd:187-254) at the
+300 MHz the tick word is quoted at.
+usage (on the GPU box): python tools/mailbox_rate.py [--calls 200]"""
 import argparse
-import importlib
+import ctypes as C
 import os
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def per_call_us(fn, calls):
+    fn()
+    best = float("inf")
+    for _ in range(3):                      # best of three batches: a request is tens of us, the host's noise is not smaller
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            fn()
+        best = min(best, (time.perf_counter() - t0) / calls)
+    return 1e6 * best
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--calls", type=int, default=20)
+    ap.add_argument("--calls", type=int, default=200)
     args = ap.parse_args()
-    nb = importlib.import_module("mini-nbody_amd")
-    print("# nbody_mailbox_run, wall time per request incl. host copies; RTL estimate = ceil(N/12) x (N + 250) clocks at 300 MHz")
-    for n in (1024, 4096, 16384, 32767):
-        pos, _ = nb.make_bodies(n)
-        rtl_ms = -(-n // 12) * (n + 250) / 300e6 * 1e3
-        eng = nb.NBody(n)
-        try:
-            for name, opts in (("RTL-faithful (REFERENCE_STRICT + FPGA16 + JSUB 1)", ((nb.OPT_ARITH, nb.ARITH_REFERENCE_STRICT), (nb.OPT_SUM_ORDER, nb.SUM_FPGA16), (nb.OPT_JSUB, 1))),
-                               ("the same, sixteen partial sums in one lane (rounds 1-3)", ((nb.OPT_WSPLIT, 1),)),
-                               ("context defaults (timed arithmetic)", ((nb.OPT_WSPLIT, -1), (nb.OPT_ARITH, nb.ARITH_FMA3), (nb.OPT_SUM_ORDER, nb.SUM_BLOCKED), (nb.OPT_JSUB, 0)))):
-                for k, v in opts:
-                    eng.set_option(k, v)
-                nb.mailbox.run(eng, nb.mailbox.encode_request(pos))
-                t0 = time.perf_counter()
-                for _ in range(args.calls):
-                    ram_a = nb.mailbox.encode_request(pos)
-                    nb.mailbox.run(eng, ram_a, clock_khz=300000)
-                ms = 1e3 * (time.perf_counter() - t0) / args.calls
-                ticks = nb.mailbox.decode_control(ram_a)["ticks"]
-                print("N = %5d  %-58s %8.3f ms per request (%7.1f G pairs/s; ticks word %d)   RTL estimate %9.2f ms = %5.0fx" %
-                      (n, name, ms, float(n) * n / ms / 1e6, ticks, rtl_ms, rtl_ms / ms))
-        finally:
-            eng.close()
+    import mini_nbody_amd as nb
+    print("# nbody_mailbox_run, wall time per request (us); RTL estimate = ceil(N/12) x (N + 250) clocks at 300 MHz")
+    print("# one context of capacity 32767 per arithmetic, every size served by it in turn")
+    sizes = (9, 100, 1024, 4096, 16384, 32767)
+    for name, faithful in (("RTL-faithful (nbody_mailbox_open(., 1))", True), ("timed arithmetic (nbody_mailbox_open(., 0))", False)):
+        with nb.Mailbox(faithful=faithful) as mb:
+            vp = C.c_void_p
+            a_own, b_own = mb.ram_a.ctypes.data_as(vp), mb.ram_b.ctypes.data_as(vp)
+            run = mb.lib.nbody_mailbox_run
+            for n in sizes:
+                pos, _ = nb.make_bodies(n)
+                rtl_us = -(-n // 12) * (n + 250) / 300e6 * 1e6
+                mb.post(pos)
+
+                def own():
+                    mb.ram_a[0, 0] = 1
+                    mb.ram_a[0, 1] = n
+                    rc = run(a_own, b_own, 300000)
+                    assert rc == 0, rc
+                us_own = per_call_us(own, args.calls)
+                ticks = int(mb.ram_a[0, 1])
+                ram_a = nb.mailbox.encode_request(pos)
+                ram_b = np.zeros((n, 4), np.float32)
+                a_any, b_any = ram_a.ctypes.data_as(vp), ram_b.ctypes.data_as(vp)
+
+                def anyb():
+                    ram_a[0, 0] = 1
+                    ram_a[0, 1] = n
+                    rc = run(a_any, b_any, 300000)
+                    assert rc == 0, rc
+                us_any = per_call_us(anyb, args.calls)
+                assert np.array_equal(ram_b.view(np.uint32), mb.ram_b[:n].view(np.uint32))
+                print("N = %5d  %-44s own RAMs %8.1f us  any buffers %8.1f us  (%7.1f G pairs/s; ticks word %d)   RTL estimate %10.1f us = %6.0fx" %
+                      (n, name, us_own, us_any, float(n) * n / us_own / 1e3, ticks, rtl_us, rtl_us / us_own))
 
 
 if __name__ == "__main__":

@@ -77,7 +77,7 @@ def main():
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             h = hashlib.sha1()
             for f in ("nbody_kernels.hpp", "force_loop_gfx950.inc", "nbody_hip.hip"):
-                h.update(open(os.path.join(root, "mini-nbody_amd", "csrc", f), "rb").read())
+                h.update(open(os.path.join(root, "mini_nbody_amd", "csrc", f), "rb").read())
             if h.hexdigest()[:12] == cfg["kernel_source_sha"]:
                 sys.path.insert(0, root)
                 import bench as _bench

@@ -5,7 +5,7 @@
 # this script points the package at libnbody_hip_diag.so through NBODY_LIB.
 # usage: tools/profile_diag.sh  (on the GPU box; output gpurun_out/prof_diag/)
 set -u
-export NBODY_LIB="${NBODY_LIB:-$PWD/mini-nbody_amd/libnbody_hip_diag.so}"
+export NBODY_LIB="${NBODY_LIB:-$PWD/mini_nbody_amd/libnbody_hip_diag.so}"
 [ -f "$NBODY_LIB" ] || { echo "missing $NBODY_LIB: run make diag"; exit 1; }
 export PHASES="${PHASES:-1 3 4 5 2 0}"
 out=gpurun_out/prof_diag

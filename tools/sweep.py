@@ -4,7 +4,6 @@ HIP-event time of the force kernels.  One process, interleaved rounds (cdna guid
 usage: python tools/sweep.py [--n N] [--steps K] [--rounds M] [--configs "smem:4:1,lds:2:4,isa1:1:8:0:sum=seq:fuse=0,..."]
 config = variant:bodies-per-lane:jsub[:waves-per-SIMD cap][:sum=seq|blocked|fpga16][:blk=K][:fuse=0|1][:long=0|1][:xcd=-1|0|1][:ws=1|4|16][:graph=K][:jsl=P (source slices, as a P-rank job cuts them)][:arith=fma3|reference|strict|refstrict]"""
 import argparse
-import importlib
 import os
 import sys
 
@@ -22,7 +21,7 @@ def main():
     ap.add_argument("--configs", default="")
     ap.add_argument("--wall", action="store_true", help="time whole steps (graph replay, no per-kernel events) instead of the force kernels")
     args = ap.parse_args()
-    nb = importlib.import_module("mini-nbody_amd")
+    import mini_nbody_amd as nb
     import numpy as np
     n = args.n
     if args.configs:
