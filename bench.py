@@ -45,10 +45,18 @@ Rank 0 prints ONE JSON line, always with:
                 (profiles/pmc_*.json, tools/profile.sh) and are attached only when that profile's recorded
                 configuration equals the run's; otherwise `traffic` is null.
   cpu_baseline  the oracle (oracle/nbody_ref.c, kind "port": the reference is VHDL and has no CPU path) timed on
-                this box's host cores, rank 0, after the timed region, on a bounded row sample — at N = 1; an N > 1 line
-                carries the object with value null (--cpu-baseline always times it there too).
-  strict_mode   (one GPU, fp32) the rate of NBODY_ARITH_STRICT — the arithmetic in which the GPU equals the CPU oracle bit for bit —
+                this box's host cores, rank 0, after the timed region, on a bounded row sample: about 15 s of host work at N = 1,
+                3 s on an N > 1 line (the other ranks wait at a barrier) — every line carries a measured value and its core count.
+One GPU: the benchmark runs in a supervised worker process (the parent never touches a GPU; --in-process for profilers).  The worker
+prints the headline line — complete, cpu_baseline included — BEFORE any study pass, then one more line after each of
+  strict_mode   (fp32) the rate of NBODY_ARITH_STRICT — the arithmetic in which the GPU equals the CPU oracle bit for bit —
                 from up to 3 steps after the timed region: what the parity claim costs on this box; never `value`.
+  configs       (the default line only) the other BASELINE configurations one GPU reaches, each {value, ms_per_step, frac}: config2 (N = 65536,
+                100 steps: the engine's default and --variant lds --tile 256), fp64 (N = 262144, 3 steps, frac against 78.6 TFLOP/s and
+                of the issue bound), config1 (N = 4096, 10 iterations: oracle/nbody_cpu beside build/nbody --strict, same checksum line);
+                at most --configs-budget (15) seconds.
+and the parent prints the LAST complete line: a study kernel that faults or hangs costs neither the headline nor the passes before it
+("extras" then says what happened).
 and for N > 1: comm_exposed_ms_per_step — how long per step the compute stream sat waiting for arriving position slices
 (HIP events around every such wait; 0 = the transfers hid behind the own-slice kernel).
 """
@@ -81,9 +89,9 @@ METRIC = "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofli
 COMM_NAMES = {0: "ring", 1: "allgather", 2: "auto", 3: "direct"}
 
 
-def cpu_baseline(n, seed, fp64):
+def cpu_baseline(n, seed, fp64, target_s=15.0):
     """The oracle timed on the host cores: a row sample (first rows x all N sources), sized to take
-    roughly 10-20 s.  Returns the JSON object."""
+    roughly target_s seconds (15 at N = 1; 3 on an N > 1 line, where the other ranks wait at a barrier).  Returns the JSON object."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
@@ -120,7 +128,6 @@ def cpu_baseline(n, seed, fp64):
     run(rows)
     t = time.perf_counter() - t0
     rate = rows * n / t
-    target_s = 15.0
     rows2 = int(min(n, max(rows, (rate * target_s / n) // 16 * 16)))
     if rows2 > rows:
         t0 = time.perf_counter()
@@ -131,6 +138,15 @@ def cpu_baseline(n, seed, fp64):
     return {"value": round(rows * n / t / 1e9, 3), "unit": "billion pair-interactions/s", "cores": cores, "kind": "port",
             "sample": "oracle/nbody_ref.c (%s), first %d of %d rows x all %d sources, %.1f s, gcc -O3 %s -fopenmp"
                       % (what, rows, n, n, t, "-march=native" if path else "-march=x86-64-v3")}
+
+
+def cpu_leg_seconds(world, mode, disabled=False):
+    """How long the host-CPU leg may take on a line of `world` GPUs (None: no leg, no `cpu_baseline` key): about 15 s of host work on a
+    one-GPU line; on an N > 1 line a 3-second row sample — every line carries a MEASURED baseline, and the other ranks sit at a barrier
+    for 3 s, not 15 — unless --cpu-baseline always asks for the long sample there too."""
+    if disabled or mode == "never":
+        return None
+    return 15.0 if (world == 1 or mode == "always") else 3.0
 
 
 def kernel_source_sha():
@@ -490,9 +506,53 @@ def supervise(worker_cmd, world, my_ranks, transport, deadline_s, rdzv_dir=None,
         shutil.rmtree(logdir, ignore_errors=True)
 
 
+def supervise_single(cmd, budget_s, extras_s, log=sys.stderr, poll=0.05):
+    """One GPU: the benchmark runs in ONE worker process and this parent, which never touches a GPU, returns the LAST complete JSON
+    line the worker printed.  The worker prints the headline — complete, cpu_baseline included — before it attempts any study pass
+    (strict arithmetic, the other BASELINE configurations) and one more line after each; so a study kernel that faults, aborts or hangs
+    costs neither the headline nor the passes finished before it: the line then says so in "extras".  Returns (exit code, object)."""
+    logdir = tempfile.mkdtemp(prefix="nbody_bench_logs_")
+    t0 = time.time()
+    proc = None
+    try:
+        proc, out_path, err_path = start_worker(cmd, 0, int(os.environ.get("LOCAL_RANK", "0")), 1, free_port(), None, logdir, 0)
+        first_line_t, extras = None, None
+        while True:
+            code = proc.poll()
+            if first_line_t is None and json_line(out_path) is not None:
+                first_line_t = time.time()
+            if code is not None:
+                if code != 0:
+                    extras = "failed: worker exited with code %d: %s" % (code, tail(err_path) or tail(out_path))
+                break
+            if first_line_t is not None and extras_s is not None and time.time() - first_line_t > extras_s:
+                extras = "timed out %.0f s after the headline line" % extras_s
+                break
+            if budget_s is not None and time.time() - t0 > budget_s:
+                extras = "timed out (budget %.0f s)" % budget_s
+                break
+            time.sleep(poll)
+        kill_group(proc)
+        lines = json_lines(out_path)
+        if not lines:
+            print("[bench supervisor] no JSON line from the worker (%s): %s" % (extras or "exit code %s" % proc.returncode, tail(err_path, 2000)), file=log, flush=True)
+            return (proc.returncode if proc.returncode not in (None, 0) else 1), None
+        obj = lines[-1]
+        if extras:
+            obj["extras"] = extras[:600]
+            print("[bench supervisor] headline kept; after it: %s" % extras, file=log, flush=True)
+        return 0, obj
+    except BaseException:
+        if proc is not None:
+            kill_group(proc)
+        raise
+    finally:
+        shutil.rmtree(logdir, ignore_errors=True)
+
+
 def supervisor_main(args, argv):
-    """-> exit code, or None when this process should run the benchmark itself (one GPU, or it IS a worker)."""
-    if os.environ.get(WORKER_ENV) or args.gpus <= 1:
+    """-> exit code, or None when this process should run the benchmark itself (it IS a worker, or --in-process)."""
+    if os.environ.get(WORKER_ENV) or (args.gpus <= 1 and args.in_process):
         return None
     t_start = time.time()
     world_env = os.environ.get("WORLD_SIZE")
@@ -502,6 +562,14 @@ def supervisor_main(args, argv):
         except ValueError:                            # not the main thread (tests call supervise() directly)
             pass
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    if args.gpus <= 1:
+        if world_env is not None and int(world_env) != 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, world_env))
+        code, obj = supervise_single(cmd, args.budget if args.budget > 0 else None, args.extras_deadline)
+        if obj is not None:
+            obj["supervisor_seconds"] = round(time.time() - t_start, 1)
+            print(json.dumps(obj), flush=True)
+        return code
     # drop a --transport given on the command line: the supervisor passes the one of the attempt
     clean = []
     skip = False
@@ -563,8 +631,8 @@ def main(argv=None):
                     help="auto: a one-GPU fp32 line also carries `strict_mode` — the rate of NBODY_ARITH_STRICT, the arithmetic that is "
                          "bit-identical to the CPU oracle, from up to 3 steps AFTER the timed region (not the timed mode, not `value`)")
     ap.add_argument("--cpu-baseline", choices=["auto", "always", "never"], default="auto",
-                    help="the oracle timed on this box's host cores after the timed region, rank 0: auto = at N = 1 only (the contract: a bounded "
-                         "sample, N = 1 only — and at N > 1 the headline line is out 10-25 s sooner); always: also at N > 1")
+                    help="the oracle timed on this box's host cores after the timed region, rank 0: auto = a ~15-s row sample at N = 1, a 3-s one "
+                         "at N > 1 (the other ranks wait at a barrier meanwhile); always: the 15-s sample at N > 1 too; never: no cpu_baseline key")
     ap.add_argument("--comm", choices=["auto", "ring", "allgather", "direct"], default="auto")
     ap.add_argument("--transport", choices=["auto", "rccl", "peer", "host"], default="auto",
                     help="how positions travel between GPUs: rccl (one process per GPU, RCCL over xGMI; auto = rccl, falling back to host when "
@@ -596,6 +664,13 @@ def main(argv=None):
     ap.add_argument("--extras", choices=["auto", "off", "forms", "all"], default="auto",
                     help="N > 1: after the headline line, time the three transfer forms (forms) and BASELINE configs[4] in fp64 (all); "
                          "auto = forms, plus config 5 when N = 8; never at N = 1")
+    ap.add_argument("--in-process", action="store_true",
+                    help="one GPU: run the benchmark in this very process instead of in a supervised worker (profilers: rocprofv3 then sees "
+                         "the kernels in the process it started)")
+    ap.add_argument("--configs-pass", choices=["auto", "never"], default="auto",
+                    help="auto: a default one-GPU fp32 line (N = 1,048,576, timed arithmetic) also carries `configs` — BASELINE configs 1 and 2 and "
+                         "the fp64 arithmetic, measured after the headline line is out, at most --configs-budget seconds")
+    ap.add_argument("--configs-budget", type=float, default=15.0)
     ap.add_argument("--config5-bodies", type=int, default=4194304, help="bodies of the extras pass's fp64 run (BASELINE configs[4]: 4,194,304)")
     args = ap.parse_args(argv)
     code = supervisor_main(args, argv)
@@ -827,32 +902,35 @@ def main(argv=None):
             out["comm_exposed_ms_per_step"] = round(wait_ms / max(1, kernel_steps), 4)
             out["comm_waits_per_step"] = round(waits / max(1, kernel_steps), 2)
             out["transport_used"] = "peer" if peer else ("rccl" if transport == "rccl" else "host")
-    if rank == 0 and world == 1 and not args.fp64 and args.strict_pass == "auto" and args.arith == "fma3":
-        out["strict_mode"] = strict_pass(eng, nb, n, dt, args.steps)
     extras = want_forms or want_c5
-    if eng is not None and not extras:
-        eng.close()
     if rank == 0:
-        cpu_leg = not args.no_cpu_baseline and (args.cpu_baseline == "always" or (args.cpu_baseline == "auto" and world == 1))
-        if not cpu_leg and not args.no_cpu_baseline and args.cpu_baseline != "never":
-            out["cpu_baseline"] = {"value": None, "unit": "billion pair-interactions/s", "cores": 0, "kind": "port",
-                                   "sample": "not timed at N > 1: the host-CPU baseline is the N = 1 run's (same box class, same workload); --cpu-baseline always times it here too"}
-        if cpu_leg:
-            # after the timed region (one GPU: with the GPU context closed); the other ranks wait at the barrier below, idle
+        target_s = cpu_leg_seconds(world, args.cpu_baseline, args.no_cpu_baseline)
+        if target_s is not None:
+            # after the timed region, on rank 0 (the other ranks wait at the barrier below, idle)
             try:
-                out["cpu_baseline"] = cpu_baseline(n, args.seed, args.fp64)
+                out["cpu_baseline"] = cpu_baseline(n, args.seed, args.fp64, target_s)
             except Exception as e:    # the GPU result is reported in any case
                 out["cpu_baseline"] = {"value": None, "unit": "billion pair-interactions/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)            # THE HEADLINE LINE — out before any extra is attempted
+        print(json.dumps(out), flush=True)            # THE HEADLINE LINE — complete, and out before any study pass or extra is attempted
     barrier()
-    if extras:
-        def publish(key, value):
-            """rank 0: one more line = headline + the extras finished so far (the supervisor takes the last complete line, so a later
-            extra that hangs cannot take an earlier one with it)"""
-            if rank == 0:
-                out[key] = value
-                print(json.dumps(out), flush=True)
 
+    def publish(key, value):
+        """rank 0: one more line = headline + the passes finished so far (the supervisor takes the last complete line, so a later
+        pass that faults or hangs cannot take the headline or an earlier pass with it)"""
+        if rank == 0:
+            out[key] = value
+            print(json.dumps(out), flush=True)
+
+    if world == 1:
+        # one GPU: the study passes, each published as it finishes
+        if not args.fp64 and args.strict_pass == "auto" and args.arith == "fma3":
+            publish("strict_mode", strict_pass(eng, nb, n, dt, args.steps))
+        eng.close()
+        default_line = (n == (1 << 20) and not args.fp64 and args.arith == "fma3" and args.variant == "auto" and args.sum == "blocked"
+                        and args.jsub == 0 and args.iblock == 0 and args.wsplit == -1)
+        if args.configs_pass == "auto" and default_line:
+            configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, args.configs_budget)
+    elif extras:
         if want_forms:
             comm_forms_pass(eng, nb, args, n, transport, run_timed, publish)
         if eng is not None:
@@ -860,8 +938,96 @@ def main(argv=None):
         if want_c5:
             publish("config5", config5_pass(nb, args, world, rank, open_engine, run_timed, roofline_of, np))
         barrier()
+    elif eng is not None:
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, budget_s):
+    """The BASELINE configurations one GPU can reach besides the headline's, on the box and in the process that timed the headline,
+    AFTER the headline line is out (never `value`):
+      config2              N = 65536 fp32, 100 steps, the engine's default kernel                     BASELINE configs[1]
+      config2_lds_tile256  the same through the north_star's form: sources tiled into LDS, tile 256   BASELINE configs[1] verbatim
+      fp64                 N = 262144 fp64, 3 steps: the arithmetic of BASELINE configs[4] (whose N = 4,194,304 over 8 GPUs is 524,288 per GPU)
+      config1              N = 4096, 10 iterations: the CPU program (oracle/nbody_cpu) beside the GPU host program in strict arithmetic
+                           (build/nbody --strict, one sequential sum per body): same checksum line          BASELINE configs[0]
+    Each entry {value, ms_per_step, frac (of the 20-flop vector roofline), ...}; the whole pass stops starting new entries once
+    budget_s seconds are spent.  A failure is recorded in the entry, not raised."""
+    t0 = time.perf_counter()
+    res = {}
+
+    def left():
+        return budget_s - (time.perf_counter() - t0)
+
+    def entry(key, make):
+        if left() < 1.0:
+            res[key] = {"value": None, "skipped": "the pass's %.0f-s budget was spent" % budget_s}
+        else:
+            try:
+                res[key] = make()
+            except Exception as ex:
+                res[key] = {"value": None, "error": repr(ex)}
+        publish("configs", dict(res))
+
+    def config2(variant, tile):
+        def make():
+            n2, steps = 65536, 100
+            with nb.NBody(n2, tile=tile) as e:
+                e.set_option(nb.OPT_VARIANT, variant)
+                pos, vel = nb.make_bodies(n2, seed=args.seed)
+                e.upload(pos, vel)
+                r = run_timed(e, steps, 5, False)
+                cfg = e.config
+                value = float(n2) * n2 * steps / r["elapsed"] / 1e9
+                return {"workload": "N=%d fp32, %d steps, 1 GPU" % (n2, steps), "value": round(value, 2), "unit": "billion pair-interactions/s",
+                        "ms_per_step": round(1e3 * r["elapsed"] / steps, 4), "frac": round(value * FLOP_PER_PAIR / 1e3 / PEAK_VECTOR_TFLOPS["f32"], 4),
+                        "kernel": {k: cfg[k] for k in ("variant", "tile", "iblock", "nseg", "wsplit", "launches_per_step")}}
+        return make
+
+    def fp64():
+        n5, steps = 262144, 3
+        with nb.NBody(n5, fp64=True) as e:
+            pos, vel = nb.make_bodies(n5, seed=args.seed, dtype=np.float64)
+            e.upload(pos, vel)
+            r = run_timed(e, steps, 1, True)
+            cfg = e.config
+            roof = roofline_of(e, cfg, r, n5, True, True)
+            value = float(n5) * n5 * steps / r["elapsed"] / 1e9
+            return {"workload": "N=%d fp64, %d steps, 1 GPU" % (n5, steps), "value": round(value, 2), "unit": "billion pair-interactions/s",
+                    "ms_per_step": round(1e3 * r["elapsed"] / steps, 3), "frac": roof["frac"], "peak_tflops": roof["peak"],
+                    "frac_of_issue_bound": roof["frac_of_issue_bound"], "kernel_ms_avg": roof["kernel_ms_avg"],
+                    "kernel": {k: cfg[k] for k in ("variant", "nseg", "wsplit", "launches_per_step")}}
+
+    def config1():
+        import re
+        cpu, gpu = os.path.join(ROOT, "oracle", "nbody_cpu"), os.path.join(ROOT, "build", "nbody")
+        missing = [os.path.relpath(x, ROOT) for x in (cpu, gpu) if not os.path.exists(x)]
+        if missing:
+            return {"value": None, "error": "missing %s: run `make host oracle`" % ", ".join(missing)}
+
+        def run(cmd):
+            o = subprocess.run(cmd, capture_output=True, text=True, timeout=max(5.0, left() + 5.0))
+            if o.returncode:
+                raise RuntimeError("%s exited with %d: %s" % (os.path.basename(cmd[0]), o.returncode, o.stderr[-300:]))
+            rate = re.search(r"average ([0-9.]+) Billion Interactions / second \(([0-9.]+) ms / step\)", o.stdout)
+            chk = [l for l in o.stdout.splitlines() if l.startswith("checksum")]
+            return float(rate.group(1)), float(rate.group(2)), chk[0] if chk else None
+        c_rate, c_ms, c_chk = run([cpu, "4096", "10"])
+        g_rate, g_ms, g_chk = run([gpu, "4096", "10", "--strict", "--sum", "seq", "--jsub", "1", "--wsplit", "1"])
+        return {"workload": "N=4096 fp32, 10 iterations (the first is warm-up), one sequential sum per body",
+                "value": g_rate, "unit": "billion pair-interactions/s", "ms_per_step": g_ms,
+                "gpu_program": "build/nbody 4096 10 --strict --sum seq --jsub 1 --wsplit 1",
+                "cpu_program": "oracle/nbody_cpu 4096 10", "cpu_value": c_rate, "cpu_ms_per_step": c_ms,
+                "checksum_gpu": g_chk, "checksum_cpu": c_chk, "checksums_equal": bool(g_chk and g_chk == c_chk)}
+
+    entry("config2", config2(nb.VARIANT_AUTO, 0))
+    entry("config2_lds_tile256", config2(nb.VARIANT_LDS, 256))
+    entry("fp64", fp64)
+    entry("config1", config1)
+    res["seconds"] = round(time.perf_counter() - t0, 2)
+    publish("configs", dict(res))
+    return res
 
 
 def strict_pass(eng, nb, n, dt, steps):

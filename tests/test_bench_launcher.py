@@ -304,3 +304,88 @@ def test_virtual_hosts_give_every_rank_its_own_host_identity(stub, tmp_path, mon
     assert code == 0 and obj["env"]["NCCL_HOSTID"] == "nbody-virtual-host-0" and obj["env"]["NCCL_SOCKET_IFNAME"] == "lo" and obj["env"]["NBODY_OVERSUBSCRIBE"] == "1"
     ids = {open(tmp_path / ("rank%d" % r)).read() for r in range(3)}
     assert ids == {"nbody-virtual-host-0", "nbody-virtual-host-1", "nbody-virtual-host-2"}
+
+
+# ---- round 5: one GPU runs in a supervised worker too; every line carries a measured cpu_baseline ---------------------------------
+
+STUB1 = textwrap.dedent('''
+    import json, os, signal, sys, time
+    assert os.environ["NBODY_BENCH_WORKER"] == "1" and os.environ["WORLD_SIZE"] == "1" and os.environ["RANK"] == "0"
+    assert "--transport" not in sys.argv
+    mode = os.environ.get("STUB_MODE", "ok")
+    if mode == "early":
+        sys.stderr.write("no usable HIP device\\n")
+        sys.exit(7)
+    line = {"metric": "stub", "n_gpus": 1, "value": 4700.0, "cpu_baseline": {"value": 59.7, "cores": 256}}
+    print("noise before the line")
+    print(json.dumps(line), flush=True)                  # the headline: complete before any study pass
+    line["strict_mode"] = {"value": 2840.0}
+    print(json.dumps(line), flush=True)
+    if mode == "fault":
+        os.kill(os.getpid(), signal.SIGSEGV)             # a study kernel takes the process down
+    if mode == "hang":
+        time.sleep(3600)
+    line["configs"] = {"config2": {"value": 4500.0}}
+    print(json.dumps(line), flush=True)
+''')
+
+
+@pytest.fixture()
+def stub1(tmp_path):
+    p = tmp_path / "stub_worker1.py"
+    p.write_text(STUB1)
+    return [sys.executable, str(p), "--gpus", "1"]
+
+
+def test_one_gpu_worker_is_supervised_and_the_last_line_wins(stub1, monkeypatch):
+    monkeypatch.setenv("STUB_MODE", "ok")
+    code, obj = bench.supervise_single(stub1, 60, 30)
+    assert code == 0 and obj["value"] == 4700.0 and obj["strict_mode"]["value"] == 2840.0 and obj["configs"]["config2"]["value"] == 4500.0
+    assert "extras" not in obj
+
+
+@pytest.mark.parametrize("mode,what", [("fault", "failed: worker exited with code -11"), ("hang", "timed out")])
+def test_a_study_pass_that_faults_or_hangs_keeps_the_headline_and_the_passes_before_it(stub1, monkeypatch, mode, what):
+    import time
+    monkeypatch.setenv("STUB_MODE", mode)
+    t0 = time.time()
+    code, obj = bench.supervise_single(stub1, 600, 1.5)
+    assert code == 0 and time.time() - t0 < 60
+    assert obj["value"] == 4700.0 and obj["cpu_baseline"]["value"] == 59.7 and obj["strict_mode"]["value"] == 2840.0
+    assert "configs" not in obj and obj["extras"].startswith(what)
+
+
+def test_a_worker_that_dies_before_its_headline_is_an_error(stub1, monkeypatch):
+    import io
+    monkeypatch.setenv("STUB_MODE", "early")
+    log = io.StringIO()
+    code, obj = bench.supervise_single(stub1, 60, 30, log=log)
+    assert code == 7 and obj is None and "no usable HIP device" in log.getvalue()
+
+
+def test_one_gpu_command_line_goes_through_the_supervisor(tmp_path):
+    """`python bench.py` (the driver's N = 1 invocation) starts a worker and prints exactly ONE line: the worker's last"""
+    stub = tmp_path / "bench.py"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    # the real supervisor code with a stub where the GPU benchmark would run
+    stub.write_text(src.replace('    if not os.path.exists(os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so")):',
+                                '    print(json.dumps({"metric": "stub", "n_gpus": 1, "worker": os.environ.get(WORKER_ENV), "argv": argv})); '
+                                'print(json.dumps({"metric": "stub", "n_gpus": 1, "second": True, "argv": argv})); return\n'
+                                '    if not os.path.exists(os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so")):', 1))
+    r = subprocess.run([sys.executable, str(stub), "--steps", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["second"] is True and lines[0]["argv"] == ["--steps", "3"] and "supervisor_seconds" in lines[0]
+    # --in-process: no worker, both lines come from this very process
+    r = subprocess.run([sys.executable, str(stub), "--in-process"], capture_output=True, text=True, timeout=120)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 2 and lines[0]["worker"] is None
+
+
+def test_every_line_gets_a_measured_cpu_baseline():
+    """VERDICT r04: an N > 1 line used to carry cpu_baseline.value null.  Now: a 3-second row sample on rank 0 (15 s at N = 1 or on request),
+    and the leg itself returns a number and the cores it used (here: a fraction of a second on this container's cores)."""
+    assert bench.cpu_leg_seconds(1, "auto") == 15.0 and bench.cpu_leg_seconds(2, "auto") == 3.0 and bench.cpu_leg_seconds(8, "auto") == 3.0
+    assert bench.cpu_leg_seconds(8, "always") == 15.0 and bench.cpu_leg_seconds(8, "never") is None and bench.cpu_leg_seconds(1, "auto", True) is None
+    cb = bench.cpu_baseline(8192, 42, False, target_s=0.3)
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "8192 sources" in cb["sample"]

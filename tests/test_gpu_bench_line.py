@@ -28,3 +28,23 @@ def test_one_gpu_line_carries_roofline_cpu_baseline_and_strict_mode():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bodies", "16384", "--steps", "4", "--strict-pass", "never", "--cpu-baseline", "never"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "strict_mode" not in json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_default_line_carries_the_other_baseline_configs():
+    """the driver's own N = 1 invocation (default bodies; few steps here) yields ONE line whose `configs` hold BASELINE
+    configs 1 and 2 and the fp64 arithmetic, measured after the headline line was out; `value` is untouched by them."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["config"]["n_bodies"] == 1 << 20 and j["value"] > 3000 and "extras" not in j, j.get("extras")
+    assert j["cpu_baseline"]["value"] > 0 and j["strict_mode"]["value"] > 0
+    c = j["configs"]
+    assert set(c) >= {"config2", "config2_lds_tile256", "fp64", "config1", "seconds"} and c["seconds"] < 40
+    for key in ("config2", "config2_lds_tile256"):
+        assert c[key]["value"] > 2000 and 0.2 < c[key]["frac"] < 0.7 and c[key]["ms_per_step"] < 3, (key, c[key])
+    assert c["config2"]["kernel"]["variant"] == "isa" and c["config2_lds_tile256"]["kernel"]["variant"] == "lds" and c["config2_lds_tile256"]["kernel"]["tile"] == 256
+    assert c["fp64"]["value"] > 500 and c["fp64"]["peak_tflops"] == 78.6 and 0.5 < c["fp64"]["frac_of_issue_bound"] <= 1.05, c["fp64"]
+    assert c["config1"]["checksums_equal"] is True and c["config1"]["cpu_value"] > 0 and c["config1"]["value"] > 0, c["config1"]
