@@ -837,7 +837,7 @@ def main(argv=None):
     autotuned = None
     if world > 1 and transport == "rccl" and args.comm == "auto" and args.overlap == 1 and args.autotune:
         # warm-up, untimed: the three transfer forms measured on THIS job's links, the fastest kept (ties: the library's default)
-        chosen, form_ms = D.autotune_comm(eng, dt)
+        chosen, form_ms = D.autotune_comm(eng, dt, restore=(pos, vel))
         args.overlap = {"ring": 2}.get(chosen, 1)
         autotuned = "autotuned in warm-up (ms per step: %s) -> %s" % (", ".join("%s %.3f" % kv for kv in form_ms.items()), chosen)
 

@@ -95,7 +95,7 @@ def comm_candidates(L):
     return [("allgather", L.COMM_ALLGATHER, 1), ("direct", L.COMM_DIRECT, 1), ("ring", L.COMM_RING, 2)]
 
 
-def autotune_comm(eng, dt=0.01, steps=2, margin=0.01, candidates=None, set_option=None):
+def autotune_comm(eng, dt=0.01, steps=2, margin=0.01, candidates=None, set_option=None, restore=None):
     """Choose the transfer form by MEASUREMENT on the job's own hardware, during warm-up: every candidate runs one untimed and
     `steps` timed steps on the live engine, the slowest rank's time counts (all-reduce MAX over the control plane), and the
     fastest form is kept — the library's default unless another one is more than `margin` faster.  Every rank makes the same
@@ -103,6 +103,9 @@ def autotune_comm(eng, dt=0.01, steps=2, margin=0.01, candidates=None, set_optio
     The result of a step does not depend on the form, only its duration does.
     Why: which form hides best behind the own-slice kernel was decided on ONE GPU with a one-rank communicator
     (profiles/r03_comm_under_load.md); the first job on real xGMI links measures it instead of trusting that.
+    The candidates advance the simulation by 1 + `steps` steps each: pass restore=(pos, vel) — the full arrays, as upload() takes them —
+    to have the state put back afterwards.  A form whose options or warm-up step raise on ANY rank is dropped by every rank together
+    (its entry reads inf).
     Returns (chosen name, {name: ms per step}); the engine is left configured with the choice."""
     import time
     import torch
@@ -114,24 +117,50 @@ def autotune_comm(eng, dt=0.01, steps=2, margin=0.01, candidates=None, set_optio
         cands = [c for c in cands if c[0] != "allgather"]
     setopt = set_option or eng.set_option
     ms = {}
+
+    def agreed_failure(failed):
+        """MAX over the ranks of a failure flag: every rank drops a form together (a rank that went on alone would wait in the next
+        barrier for the ones that raised)"""
+        t = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t[0] > 0)
+
     for name, comm, overlap in cands:
-        setopt(L.OPT_COMM, comm)
-        setopt(L.OPT_OVERLAP, overlap)
-        eng.step(dt, 1)
-        eng.sync()
+        failed = False
+        try:
+            setopt(L.OPT_COMM, comm)
+            setopt(L.OPT_OVERLAP, overlap)
+            eng.step(dt, 1)
+            eng.sync()
+        except Exception:          # (a rank that raises INSIDE a collective leaves its peers in it: that case is the supervisor's deadline)
+            failed = True
+        if agreed_failure(failed):
+            ms[name] = float("inf")
+            continue
         dist.barrier()
         t0 = time.perf_counter()
-        eng.step(dt, steps)
-        eng.sync()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        try:
+            eng.step(dt, steps)
+            eng.sync()
+            el = time.perf_counter() - t0
+        except Exception:
+            el = float("inf")
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms[name] = float(t[0]) * 1e3 / steps
-    best = cands[0][0]
-    for name, _, _ in cands[1:]:
+    ok = [c for c in cands if ms[c[0]] != float("inf")]
+    if not ok:
+        raise RuntimeError("no transfer form completed its warm-up steps: %r" % (ms,))
+    best = ok[0][0]
+    for name, _, _ in ok[1:]:
         if ms[name] < ms[best] * (1.0 - margin):
             best = name
     for name, comm, overlap in cands:
         if name == best:
             setopt(L.OPT_COMM, comm)
             setopt(L.OPT_OVERLAP, overlap)
+    if restore is not None:
+        # the candidates ran (1 + steps) steps each on the live engine: put the caller's state back, so that an autotuned run enters its
+        # timed region from the same state as a default one
+        eng.upload(*restore)
     return best, ms

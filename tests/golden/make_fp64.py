@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Generate tests/golden/fp64_n64.json — a checked fixture for the fp64 path (BASELINE configs[4]'s arithmetic).
 
-The fp64 kernels are held to tolerances only (there is no strict fp64 mode: 1/sqrt is v_rsq_f64 + one third-order step), so an
-fp64 summation-order slip of last-bit size would be invisible to an oracle-vs-engine comparison in which both round alike.  This
-fixture is a third statement: F_i = sum_j (r_j - r_i) (|r_j - r_i|^2 + eps)^(-3/2) over all j including i (S/top_level.vhd:233-254,
+The timed fp64 arithmetic is held to tolerances (its inverse cube is v_rsq_f64 + one third-order step, not the oracle's IEEE chain;
+the fp64 NBODY_ARITH_STRICT mode of round 4 IS bit-identical to the oracle, tests/test_golden_fp64.py), and an oracle-vs-engine
+comparison in which both round alike cannot see a slip both share.  This fixture is a third statement: F_i = sum_j (r_j - r_i) (|r_j - r_i|^2 + eps)^(-3/2) over all j including i (S/top_level.vhd:233-254,
 S/fxyz.vhd:97-127, eps = (double)1e-9f = 0x3089705F widened, S/dzsoft.vhd:177) evaluated in 60-digit decimal arithmetic — every
 binary64 input is exact in it — and rounded ONCE to binary64 per component.  Consumers (tests/test_golden_fp64.py) bound the engine's
 and the oracle's error per row in ulps of that row's largest component.

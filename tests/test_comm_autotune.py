@@ -30,24 +30,27 @@ WORKER = textwrap.dedent("""
         n = {n}
         def __init__(self): self.opt = {{}}; self.log = []
         def set_option(self, k, v): self.opt[k] = v
+        def upload(self, pos, vel): self.log.append(("upload", pos, vel))
         def step(self, dt, k):
             form = names[self.opt[L.OPT_COMM]]
+            if {fail!r} == [form, rank]:
+                raise RuntimeError("RCCL error 5 in form %s" % form)
             self.log.append((form, self.opt[L.OPT_OVERLAP], k))
             time.sleep(cost[form][rank] * k)
         def sync(self): pass
 
     e = Stub()
-    best, ms = D.autotune_comm(e, 0.01, steps=2, margin={margin})
+    best, ms = D.autotune_comm(e, 0.01, steps=2, margin={margin}, restore={restore!r})
     json.dump({{"best": best, "ms": ms, "left": [names[e.opt[L.OPT_COMM]], e.opt[L.OPT_OVERLAP]], "log": e.log}}, open({out!r} + "%d.json" % rank, "w"))
     dist.barrier(); dist.destroy_process_group()
 """)
 
 
-def run(tmp_path, cost, n=1000, margin=0.01):
+def run(tmp_path, cost, n=1000, margin=0.01, fail=None, restore=None):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "r")
     script = tmp_path / "w.py"
-    script.write_text(WORKER.format(root=ROOT, cost=cost, n=n, margin=margin, out=out))
+    script.write_text(WORKER.format(root=ROOT, cost=cost, n=n, margin=margin, out=out, fail=fail, restore=restore))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     for p in procs:
@@ -71,3 +74,14 @@ def test_ties_keep_the_default_and_ragged_slices_drop_the_all_gather(tmp_path):
     assert a["best"] == b["best"] == "allgather" and a["left"] == ["allgather", 1]          # 4 % faster is inside the margin
     a, b = run(tmp_path, {"allgather": [0.001, 0.001], "direct": [0.05, 0.05], "ring": [0.02, 0.02]}, n=1001)
     assert "allgather" not in a["ms"] and a["best"] == b["best"] == "ring"                  # 1001 bodies over 2 ranks: no equal slices
+
+
+def test_a_form_that_fails_on_one_rank_is_dropped_by_all_and_the_state_is_put_back(tmp_path):
+    """the "direct" form raises on rank 1 only; rank 0 must not go on to time it alone (it would wait in the barrier for a rank
+    that left) — both drop it, agree on the best of the rest, and both put the caller's state back after the candidates' steps."""
+    a, b = run(tmp_path, {"allgather": [0.05, 0.06], "direct": [0.001, 0.001], "ring": [0.02, 0.03]}, fail=["direct", 1], restore=("POS", "VEL"))
+    assert a["best"] == b["best"] == "ring" and a["ms"]["direct"] == b["ms"]["direct"] == float("inf")
+    assert a["left"] == b["left"] == ["ring", 2]
+    for r in (a, b):
+        assert r["log"][-1] == ["upload", "POS", "VEL"]
+        assert [x[0] for x in r["log"][:-1]].count("direct") == (1 if r is a else 0)     # rank 0 ran the untimed step only; rank 1 raised in it

@@ -88,3 +88,37 @@ def test_engine_fp64_strict_equals_the_oracle_and_the_fixture_bounds_both(nb, or
             assert row_ulps(got, f).max() <= BOUND_ULP
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_inverse_cube_of_the_timed_fp64_arithmetic_over_the_whole_range_of_d2(nb, capsys):
+    """inv3_f64 (csrc/nbody_kernels.hpp: v_rsq_f64 seed + ONE third-order step on the cube, six operations) was pinned only
+    by the N = 64 fixture's 8-ulp bound.  Here per PAIR, over d2 from the softening (1e-9) to 1e12 with random significands: a two-body
+    system at separation d along a random direction gives F_0 = d * inv3(d2) (the self term adds 0), so the timed arithmetic and the
+    strict one (IEEE square root and divide, then inv * (inv * inv): the oracle's expression) must agree to a few ulps of the largest
+    component — <= 4: the strict chain's own five roundings are the larger part of that."""
+    rng = np.random.default_rng(5)
+    m = 3000
+    mag = 10.0 ** rng.uniform(-6.0, 6.0, m)
+    direction = rng.normal(size=(m, 3))
+    direction /= np.linalg.norm(direction, axis=1)[:, None]
+    sep = direction * mag[:, None] * rng.uniform(1.0, 2.0, (m, 1))
+    worst = 0.0
+    with nb.NBody(2, fp64=True) as eng:
+        got = {}
+        for arith in (nb.ARITH_FMA3, nb.ARITH_STRICT):
+            eng.set_option(nb.OPT_ARITH, arith)
+            out = np.empty((m, 3))
+            pos = np.zeros((2, 4))
+            pos[:, 3] = 1.0
+            for k in range(m):
+                pos[1, :3] = sep[k]
+                out[k] = eng.forces(pos)[0, :3]
+            got[arith] = out
+        a, b = got[nb.ARITH_FMA3], got[nb.ARITH_STRICT]
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        ulp = np.spacing(np.abs(b).max(axis=1))
+        worst = float((np.abs(a - b).max(axis=1) / ulp).max())
+    with capsys.disabled():
+        print("\n[fp64 inverse cube] %d pairs, d2 in [1e-12, 4e12]: timed arithmetic vs IEEE chain, worst %.2f ulp of the pair's largest component" % (m, worst))
+    assert worst <= 4.0

@@ -763,59 +763,70 @@ def shard_edge_rows(n, shards, width):
     return out
 
 
+_HEADLINE = {}
+
+
+def headline_reference(nb, oracle_fast, eng):
+    """ONE CPU pass over the headline size for the whole session (1.1e12 pairs: under a minute on the GPU box's host): the oracle's forces on
+    every row of the seeded N = 1,048,576 state in the order the engine's timed configuration sums in.  Both headline-size tests read it."""
+    import time
+    if "want" not in _HEADLINE:
+        n = 1 << 20
+        pos, vel = nb.make_bodies(n)
+        t0 = time.time()
+        _HEADLINE.update(pos=pos, vel=vel, order=eng.order, want=oracle_forces(oracle_fast, eng, pos))
+        _HEADLINE["t_cpu"] = time.time() - t0
+    assert _HEADLINE["order"] == eng.order
+    return _HEADLINE
+
+
 def test_headline_size_every_row(nb, oracle_fast, engine_factory, capsys):
     """N = 1,048,576 in the configuration bench.py times, EVERY row (round 4: the host of the GPU box has the cores for one full CPU pass
     — 1.1e12 pairs, under a minute on 256 threads — so the headline size need not be row-sampled): strict arithmetic bit-identical to the
     oracle on all 1,048,576 rows; the timed arithmetic within 1e-5 of the same-order oracle on every row, relative to that row's own force."""
-    import time
     n = 1 << 20
-    pos, _ = nb.make_bodies(n)
     eng = engine_factory(n)
     cfg = eng.config
     assert cfg["variant"] == "isa" and cfg["nseg"] == 8 and cfg["sum_block"] == 1024 and cfg["launches_per_step"] == 1 and cfg["wsplit"] == 4
-    t0 = time.time()
-    want = oracle_forces(oracle_fast, eng, pos)
-    t_cpu = time.time() - t0
+    ref = headline_reference(nb, oracle_fast, eng)
+    pos, want = ref["pos"], ref["want"]
     fast = eng.forces(pos)
     r = row_rel(fast, want)
     eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
-    assert eng.config["nseg"] == 8 and eng.order == {k: v for k, v in eng.order.items()}
+    assert eng.config["nseg"] == 8 and eng.order == ref["order"]
     strict = eng.forces(pos)
     with capsys.disabled():
-        print("\n[config 3, every row] N=1048576: strict == oracle on all rows: %s; timed arithmetic worst row %.2e, 99.9 %% %.2e (CPU pass %.0f s)"
-              % (np.array_equal(bits(strict), bits(want)), r.max(), np.quantile(r, 0.999), t_cpu))
+        print("\n[config 3, every row] N=1048576: strict (%s loop) == oracle on all rows: %s; timed arithmetic worst row %.2e, 99.9 %% %.2e (CPU pass %.0f s)"
+              % (eng.config["variant"], np.array_equal(bits(strict), bits(want)), r.max(), np.quantile(r, 0.999), ref["t_cpu"]))
     assert np.array_equal(bits(strict), bits(want))
     assert r.max() < TOL
 
 
-def test_headline_size_row_sample_and_properties(nb, oracle_fast, engine_factory, capsys):
-    """N = 1,048,576 (BASELINE config 3) in the configuration bench.py times (ISA loop, 8 source segments, blocked sums,
-    one launch per step): one CPU pass is 1.1e12 pairs, so parity is row-sampled (SURVEY.md §7 "Hard parts") — 1280 rows:
-    the first and last 64 rows of each of 8 shards of 131072 (the 8-GPU shard edges) plus 256 in the middle, all N sources.
-    Strict: bit-exact.  Fast: every sampled row within 1e-5 of the same-order oracle AND of fp64.  Then size-independent
-    properties of one timed-mode step on the full state."""
+def test_headline_size_row_windows_and_properties(nb, oracle_fast, engine_factory, capsys):
+    """N = 1,048,576 (BASELINE config 3) in the configuration bench.py times, through the ROW-WINDOW entry point (nbody_forces_rows: what a
+    sharded job checks itself with) on 1280 rows — the first and last 64 rows of each of 8 shards of 131072 (the 8-GPU shard edges) plus
+    256 in the middle, all N sources: strict windows bit-identical to the session's one CPU pass (headline_reference), the timed arithmetic
+    within 1e-5 of it and of fp64.  Then size-independent properties of one timed-mode step on the full state."""
     n = 1 << 20
-    pos, vel = nb.make_bodies(n)
     eng = engine_factory(n)
     cfg = eng.config
     assert cfg["variant"] == "isa" and cfg["nseg"] == 8 and cfg["sum_block"] == 1024 and cfg["launches_per_step"] == 1
+    ref = headline_reference(nb, oracle_fast, eng)
+    pos, vel, want_all = ref["pos"], ref["vel"], ref["want"]
     eng.upload(pos, vel)
     sample = shard_edge_rows(n, 8, 64) + [(n // 2 - 128, 256)]
     assert sum(c for _, c in sample) >= 1024
     eng.set_option(nb.OPT_ARITH, nb.ARITH_STRICT)
     assert eng.config["nseg"] == 8
     for first, cnt in sample:
-        got = eng.forces_rows(first, cnt)
-        want = oracle_forces(oracle_fast, eng, pos[first:first + cnt], pos)
-        assert np.array_equal(bits(got), bits(want)), first
+        assert np.array_equal(bits(eng.forces_rows(first, cnt)), bits(want_all[first:first + cnt])), first
     eng.set_option(nb.OPT_ARITH, nb.ARITH_FMA3)
     assert eng.config == cfg
     worst_same = worst_f64 = 0.0
     for first, cnt in sample:
         got = eng.forces_rows(first, cnt)
-        want = oracle_forces(oracle_fast, eng, pos[first:first + cnt], pos)
         f64 = oracle_fast.forces_f64_from_f32(pos[first:first + cnt], pos)
-        worst_same = max(worst_same, row_rel(got, want).max())
+        worst_same = max(worst_same, row_rel(got, want_all[first:first + cnt]).max())
         worst_f64 = max(worst_f64, row_rel(got, f64).max())
     with capsys.disabled():
         print("\n[config 3] N=1048576 timed configuration %s: worst sampled row vs same-order oracle %.2e, vs fp64 %.2e" % (cfg, worst_same, worst_f64))
