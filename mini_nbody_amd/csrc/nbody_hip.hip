@@ -172,11 +172,8 @@ void resolve_config() {
   if (g.fp64 && g.variant != NBODY_VARIANT_ISA) g.variant = NBODY_VARIANT_SMEM;   // fp64: ISA loop or the compiled SMEM kernel
   // fp64 strict arithmetic (IEEE sqrt and divide: bit-identical to the oracle) exists in the compiled kernel only
   if (g.fp64 && (g.opt.arith & 2)) g.variant = NBODY_VARIANT_SMEM;
-  // the hand-scheduled fp32 loops exist for the timed arithmetic and (round 5) for NBODY_ARITH_STRICT, in the engine's own summation
-  // orders; the RTL's rounding points and the FPGA order use the C++ kernels.  NBODY_STRICT_LOOP=0: the compiled strict kernel (A/B)
-  static const bool strict_isa = !(getenv("NBODY_STRICT_LOOP") && atoi(getenv("NBODY_STRICT_LOOP")) == 0);
-  const bool isa_arith = g.opt.arith == NBODY_ARITH_FMA3 || (g.opt.arith == NBODY_ARITH_STRICT && !g.fp64 && strict_isa && g.opt.isa_phase <= 1);
-  if (g.variant == NBODY_VARIANT_ISA && (!isa_arith || g.opt.sum_order == NBODY_SUM_FPGA16)) g.variant = NBODY_VARIANT_SMEM;
+  // the hand-scheduled loops exist for the timed arithmetic only; the study modes use the C++ kernels
+  if (g.variant == NBODY_VARIANT_ISA && (g.opt.arith != NBODY_ARITH_FMA3 || g.opt.sum_order == NBODY_SUM_FPGA16)) g.variant = NBODY_VARIANT_SMEM;
   int R = g.opt.iblock;
   if (R == 0) R = (g.variant == NBODY_VARIANT_LDS || g.variant == NBODY_VARIANT_READLANE) ? 2 : 1;
   if (g.variant == NBODY_VARIANT_ISA) R = 1;
@@ -531,21 +528,6 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
       case NBODY_ARITH_REFERENCE_STRICT: return launch_timed(L, force_fpga16_f32<3>, grid, a);
       default: return launch_timed(L, force_fpga16_f32<0>, grid, a);
     }
-  }
-  if (g.variant == NBODY_VARIANT_ISA && g.opt.arith == NBODY_ARITH_STRICT) {   // the strict 1/sqrt inside the hand-scheduled loop (4-body buffers)
-    a.long_buffers = 0;
-#ifdef NBODY_DIAG_LOOPS
-    {   // TIMING-ONLY forms of the strict loop (tools/gen_force_loop.py body_strict): NBODY_STRICT_FORM = 1 no branch, 2 no compare either, 3 VOPC compare
-      static const int form = getenv("NBODY_STRICT_FORM") ? atoi(getenv("NBODY_STRICT_FORM")) : 0;
-      if (form == 1 && a.wsplit == 4) return launch_timed(L, force_isa_strict_f32<4, 2>, grid, a);
-      if (form == 2 && a.wsplit == 4) return launch_timed(L, force_isa_strict_f32<4, 3>, grid, a);
-      if (form == 3 && a.wsplit == 4) return launch_timed(L, force_isa_strict_f32<4, 4>, grid, a);
-      if (form == 4 && a.wsplit == 4) return launch_timed(L, force_isa_strict_f32<4, 5>, grid, a);
-      if (form == 5 && a.wsplit == 4) return launch_timed(L, force_isa_strict_f32<4, 6>, grid, a);
-    }
-#endif
-    if (a.wsplit == 16) return launch_timed(L, force_isa_strict_f32<16>, grid, a);
-    return a.wsplit == 4 ? launch_timed(L, force_isa_strict_f32<4>, grid, a) : launch_timed(L, force_isa_strict_f32<1>, grid, a);
   }
   if (g.variant == NBODY_VARIANT_ISA) {   // one body per lane, fast arithmetic only (resolve_config guarantees both)
     if (a.long_buffers) {

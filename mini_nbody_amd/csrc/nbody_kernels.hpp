@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(wg_threads(WS)) force_smem_f32(ForceArgs a) {
 // SGPR budgets: 81-96 SGPRs leave room for 7 waves per SIMD, <= 80 for 8 (MI355X_MICROARCH.md, "Occupancy API" row).  The
 // product loop's scalars end at s71 (78-79 with VCC etc.: 8 waves); the long-buffer loop holds 64 buffer SGPRs (106: 6-7 waves),
 // which is why it is a kernel of its own.
-template <int PLACEMENT, int LONG, int WS, int STRICT = 0>
+template <int PLACEMENT, int LONG, int WS>
 __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_sums)[64]) {
   int seg, jb, je, i;
   wave_work<1, WS>(a, &seg, &jb, &je, &i);
@@ -719,21 +719,7 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_s
                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [bx] "+v"(bx), [by] "+v"(by), [bz] "+v"(bz)            \
                    : [xi] "v"(xi), [yi] "v"(yi), [zi] "v"(zi), [eps] "s"(eps), [p] "s"(p), [groups] "s"(groups), [blk] "s"(blk) \
                    : CLOBBERS)
-    if constexpr (STRICT) {
-      // NBODY_ARITH_STRICT (round 5): the product loop's structure and placement around the strict 1/sqrt — 19 full-rate VALU + v_rsq_f32
-      // per pair, the IEEE form out of line behind a never-taken branch (tools/gen_force_loop.py body_strict).  Same operations in the
-      // same order as pair_f32<kArithStrict>: same bits as force_smem_f32<1, 2, WS>.
-      static_assert(!LONG && PLACEMENT == 1, "one strict loop form");
-#ifdef NBODY_DIAG_LOOPS
-      if constexpr (STRICT == 2) { NB_RUN_LOOP(NB_FORCE_LOOP_STRICT_D1, NB_FORCE_LOOP_STRICT_CLOBBERS); }        // TIMING ONLY: no branch
-      else if constexpr (STRICT == 3) { NB_RUN_LOOP(NB_FORCE_LOOP_STRICT_D2, NB_FORCE_LOOP_STRICT_CLOBBERS); }   // TIMING ONLY: no compare, no branch
-      else if constexpr (STRICT == 4) { NB_RUN_LOOP(NB_FORCE_LOOP_STRICT_D3, NB_FORCE_LOOP_STRICT_CLOBBERS); }   // 4-byte compare + branch
-      else if constexpr (STRICT == 5) { NB_RUN_LOOP(NB_FORCE_LOOP_STRICT_D4, NB_FORCE_LOOP_STRICT_CLOBBERS); }   // constants from VGPRs (bit-exact)
-      else if constexpr (STRICT == 6) { NB_RUN_LOOP(NB_FORCE_LOOP_STRICT_D5, NB_FORCE_LOOP_STRICT_CLOBBERS); }   // ... and eps
-      else
-#endif
-      NB_RUN_LOOP(NB_FORCE_LOOP_STRICT, NB_FORCE_LOOP_STRICT_CLOBBERS);
-    } else if constexpr (LONG) {   // its own kernel: the 64 buffer SGPRs would cost the product loop its 8th resident wave
+    if constexpr (LONG) {   // its own kernel: the 64 buffer SGPRs would cost the product loop its 8th resident wave
       NB_RUN_LOOP(NB_FORCE_LOOP_LONG, NB_FORCE_LOOP_LONG_CLOBBERS);
     } else if constexpr (PLACEMENT == 0) {   // the product loop one 4-byte placement phase off (kept to re-measure that effect)
       NB_RUN_LOOP(NB_FORCE_LOOP_V0, NB_FORCE_LOOP_CLOBBERS);
@@ -795,7 +781,7 @@ __device__ __forceinline__ void force_isa_f32_body(const ForceArgs& a, f4 (*ws_s
   // last, unfinished block (sum_block is a multiple of 64, so a block never ends inside them).
   for (; j < je; ++j) {
     f4 q = src[j];
-    pair_f32<STRICT ? kArithStrict : 0>(q.x, q.y, q.z, xi, yi, zi, eps, ax, ay, az);
+    pair_f32<0>(q.x, q.y, q.z, xi, yi, zi, eps, ax, ay, az);
   }
   s.ax[0] = ax; s.ay[0] = ay; s.az[0] = az; s.bx[0] = bx; s.by[0] = by; s.bz[0] = bz;
   s.close(blocked, blocked && (count % a.sum_block) != 0);
@@ -808,9 +794,6 @@ __global__ void __launch_bounds__(wg_threads(WS), WS == 16 ? 8 : 1)   // (thread
 force_isa_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<PLACEMENT, 0, WS>(a, ws_sums); }
 template <int WS>
 __global__ void __launch_bounds__(wg_threads(WS)) force_isa_long_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<1, 1, WS>(a, ws_sums); }
-template <int WS, int FORM = 1>     // FORM > 1: timing-only diagnostic forms of the diagnostic build
-__global__ void __launch_bounds__(wg_threads(WS), WS == 16 ? 8 : 1)
-force_isa_strict_f32(ForceArgs a) { NB_WS_LDS(f4, WS); force_isa_f32_body<1, 0, WS, FORM>(a, ws_sums); }
 
 // ---------------------------------------------------------------------------
 // LDS variant (the north_star's "source bodies tiled into LDS", tile = 256 by

@@ -154,122 +154,6 @@ def body(k, sbase, b, style="fmaak"):
     ]
 
 
-# ---- the STRICT arithmetic (NBODY_ARITH_STRICT, round 5): the same pair with 1/sqrt as rsqrt_strict_f32 of nbody_kernels.hpp evaluates it —
-# v_rsq_f32 seed y, the residual e = 1 - x y^2 from an exact product pair, ONE fma y + (y e)/2 evaluated twice with the factor 1/2 widened and
-# narrowed by 2^-16; where the two agree (all but ~2^-16 of arguments) that is (float)(1.0 / sqrt((double)x)), where they differ a lane
-# needs the IEEE form: v_cmp_neq + s_cbranch_vccnz to an OUT-OF-LINE block (one per body of the iteration, registers baked in) that
-# evaluates binary64 square root and divide for the whole wave as hipcc expands them (v_rsq_f64 / v_rcp_f64 seeds, Newton steps,
-# div_scale / div_fmas / div_fixup: correctly rounded, hence unique) and selects it for the lanes whose two fmas differed.  Per pair
-# 19 full-rate VALU + v_rsq_f32 = 46 issue cycles and one never-taken scalar branch (paired with an s_nop: the 8-byte phase holds).
-S_Y, S_HI, S_LO, S_E, S_R, S_R2 = 19, 26, 28, 30, 32, 34      # y odd: fma(t even, y, -hi even) and fma(-lo even, y, e even) never read three of a kind
-S_K_WIDE, S_K_NARROW = 0x3F000100, 0x3EFFFE00               # 1/2 + 2^-16, 1/2 - 2^-16 (kStrictBand in nbody_kernels.hpp)
-S_D0, S_D1, S_D2, S_D3, S_D4 = 36, 38, 40, 42, 44            # binary64 temporaries of the out-of-line block (pairs)
-S_A, S_B, S_C = 48, 49, 50                                   # v48, v49 singles; v[50:51] the scaling threshold
-S_KW_V, S_KN_V, S_ONE_V = 33, 35, 11                         # experiment forms 4, 5: the constants in VGPRs (odd: beside tt even / y odd, hi even / y odd)
-
-
-STRICT_FORM = 0     # 0: the product form; 1-3: TIMING-ONLY diagnostic forms (diag build), see main()
-
-
-def body_strict(k, sbase, b, site):
-    out = body_strict_product(k, sbase, b, site)
-    if STRICT_FORM == 1:      # no branch pair (a lane that needs the IEEE form keeps the fast value: wrong for ~2^-16 of pairs)
-        out = [i for i in out if not i.startswith("s_cbranch_vccnz") and i != "s_nop 0"]
-    elif STRICT_FORM == 2:    # neither compare nor branch
-        out = [i for i in out if not i.startswith("s_cbranch_vccnz") and i != "s_nop 0" and not i.startswith("v_cmp_neq")]
-    elif STRICT_FORM == 3:    # the compare in its 4-byte VOPC encoding, paired with the 4-byte branch (no s_nop)
-        out = [i.replace("v_cmp_neq_f32_e64 vcc,", "v_cmp_neq_f32_e32 vcc,") for i in out if i != "s_nop 0"]
-    elif STRICT_FORM in (4, 5):   # bit-exact: the two band factors and 1.0 (5: eps too) from VGPRs instead of literals / the inline constant
-        out = [i.replace("v_fmamk_f32 v%d, v%d, 0x%08x, v%d" % (S_R, S_HI, S_K_WIDE, S_Y), "v_fma_f32 v%d, v%d, v%d, v%d" % (S_R, S_HI, S_KW_V, S_Y))
-                .replace("v_fmamk_f32 v%d, v%d, 0x%08x, v%d" % (S_R2, S_HI, S_K_NARROW, S_Y), "v_fma_f32 v%d, v%d, v%d, v%d" % (S_R2, S_HI, S_KN_V, S_Y))
-                .replace("v%d, 1.0" % S_Y, "v%d, v%d" % (S_Y, S_ONE_V)) for i in out]
-        if STRICT_FORM == 5:
-            out = [re.sub(r"v_fmaak_f32 (v\d+), (v\d+), (v\d+), 0x%08x" % SOFT_BITS, r"v_fma_f32 \1, \2, \3, %s" % EPSV, i) for i in out]
-    return out
-
-
-def body_strict_product(k, sbase, b, site):
-    t, tp = T2[k & 1], T2[(k - 1) & 1]
-    dx, dy, dz = DSETS[k & 1]
-    px, py, pz = DSETS[(k - 1) & 1]
-    s0 = sbase + 4 * b
-    return [
-        "v_sub_f32_e64 v%d, s%d, %s" % (dx, s0, XI), "v_sub_f32_e64 v%d, s%d, %s" % (dy, s0 + 1, YI), "v_sub_f32_e64 v%d, s%d, %s" % (dz, s0 + 2, ZI),
-        "v_fmaak_f32 v%d, v%d, v%d, 0x%08x" % (t, dz, dz, SOFT_BITS),
-        "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dy, dy, t), "v_fma_f32 v%d, v%d, v%d, v%d" % (t, dx, dx, t),
-        "v_rsq_f32_e64 v%d, v%d" % (S_Y, t),                                         # y: the seed (x = d2 stays in t)
-        "v_fma_f32 %s, v%d, v%d, %s" % (AX, px, tp, AX), "v_fma_f32 %s, v%d, v%d, %s" % (AY, py, tp, AY),
-        "v_fma_f32 %s, v%d, v%d, %s" % (AZ, pz, tp, AZ),                             # the previous body's accumulates: the wait state
-        "v_mul_f32_e64 v%d, v%d, v%d" % (S_HI, t, S_Y),                              # hi = x y
-        "v_fma_f32 v%d, v%d, v%d, -v%d" % (S_LO, t, S_Y, S_HI),                      # lo = fma(x, y, -hi): hi + lo = x y exactly
-        "v_fma_f32 v%d, -v%d, v%d, 1.0" % (S_E, S_HI, S_Y),                          # e = fma(-hi, y, 1)
-        "v_fma_f32 v%d, -v%d, v%d, v%d" % (S_E, S_LO, S_Y, S_E),                     # e = fma(-lo, y, e)
-        "v_mul_f32_e64 v%d, v%d, v%d" % (S_HI, S_Y, S_E),                            # t = y e
-        "v_fmamk_f32 v%d, v%d, 0x%08x, v%d" % (S_R, S_HI, S_K_WIDE, S_Y),            # r  = fma(t, 1/2 + 2^-16, y)
-        "v_fmamk_f32 v%d, v%d, 0x%08x, v%d" % (S_R2, S_HI, S_K_NARROW, S_Y),         # r2 = fma(t, 1/2 - 2^-16, y)
-        "v_cmp_neq_f32_e64 vcc, v%d, v%d" % (S_R, S_R2),                             # also true for NaN (x = inf, NaN, negative)
-        "s_cbranch_vccnz %df" % (40 + site), "s_nop 0",
-        "%d:" % (50 + site),
-        "v_mul_f32_e64 v%d, v%d, v%d" % (U, S_R, S_R),                               # S/cube.vhd:66-67
-        "v_mul_f32_e64 v%d, v%d, v%d" % (t, S_R, U),                                 # S/cube.vhd:69-70: inv3 over x, which is dead now
-    ]
-
-
-def strict_stub(k, site):
-    """out of line: the lanes of the wave whose two fmas differ get (float)(1.0 / sqrt((double)x)) as hipcc expands the two binary64 operations"""
-    t = T2[k & 1]
-    d0, d1, d2, d3, d4 = (vp(r) for r in (S_D0, S_D1, S_D2, S_D3, S_D4))
-    return [
-        "%d:" % (40 + site),
-        "v_cvt_f64_f32_e32 %s, v%d" % (d0, t),
-        "v_mov_b32 v%d, 0" % S_C, "v_mov_b32 v%d, 0x10000000" % (S_C + 1),          # 2^-767: below it the argument is scaled by 2^256
-        "v_cmp_lt_f64_e64 vcc, %s, %s" % (d0, vp(S_C)), "s_nop 3",
-        "v_mov_b32 v%d, 0x100" % S_A, "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (S_A, S_A),
-        "v_mov_b32 v%d, 0xffffff80" % S_B, "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (S_B, S_B),
-        "v_ldexp_f64 %s, %s, v%d" % (d0, d0, S_A),
-        "v_rsq_f64_e32 %s, %s" % (d1, d0), "s_nop 1",
-        "v_mov_b32 v%d, 0x260" % S_A, "v_cmp_class_f64_e32 vcc, %s, v%d" % (d0, S_A),  # +-0, +inf: the square root is the argument
-        "v_mul_f64 %s, %s, %s" % (d2, d0, d1), "v_mul_f64 %s, %s, 0.5" % (d1, d1),
-        "v_fma_f64 %s, -%s, %s, 0.5" % (d3, d1, d2),
-        "v_fma_f64 %s, %s, %s, %s" % (d2, d2, d3, d2), "v_fma_f64 %s, %s, %s, %s" % (d1, d1, d3, d1),
-        "v_fma_f64 %s, -%s, %s, %s" % (d3, d2, d2, d0), "v_fma_f64 %s, %s, %s, %s" % (d2, d3, d1, d2),
-        "v_fma_f64 %s, -%s, %s, %s" % (d3, d2, d2, d0), "v_fma_f64 %s, %s, %s, %s" % (d2, d3, d1, d2),
-        "v_ldexp_f64 %s, %s, v%d" % (d1, d2, S_B),
-        "v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (S_D0 + 1, S_D1 + 1, S_D0 + 1), "v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (S_D0, S_D1, S_D0),   # sqrt(x)
-        "v_div_scale_f64 %s, vcc, %s, %s, 1.0" % (d1, d0, d0),
-        "v_rcp_f64_e32 %s, %s" % (d2, d1), "s_nop 1",
-        "v_div_scale_f64 %s, vcc, 1.0, %s, 1.0" % (d3, d0),
-        "v_fma_f64 %s, -%s, %s, 1.0" % (d4, d1, d2), "v_fma_f64 %s, %s, %s, %s" % (d2, d2, d4, d2),
-        "v_fma_f64 %s, -%s, %s, 1.0" % (d4, d1, d2), "v_fma_f64 %s, %s, %s, %s" % (d2, d2, d4, d2),
-        "v_mul_f64 %s, %s, %s" % (d4, d3, d2),
-        "v_fma_f64 %s, -%s, %s, %s" % (d1, d1, d4, d3), "s_nop 3",
-        "v_div_fmas_f64 %s, %s, %s, %s" % (d1, d1, d2, d4),
-        "v_div_fixup_f64 %s, %s, %s, 1.0" % (d0, d1, d0),                           # 1.0 / sqrt(x)
-        "v_cvt_f32_f64_e32 v%d, %s" % (S_A, d0),
-        "v_cmp_neq_f32_e64 vcc, v%d, v%d" % (S_R, S_R2), "s_nop 3",
-        "v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (S_R, S_R, S_A),
-        "s_branch %db" % (50 + site),
-    ]
-
-
-def build_strict(pad, form=0):
-    """the product loop's structure (build()) around body_strict, the eight out-of-line blocks after the loop's exit"""
-    global STRICT_FORM
-    STRICT_FORM = form
-    try:
-        ins = build(pad, style="strict")
-    finally:
-        STRICT_FORM = 0
-    if form in (4, 5):
-        at = ins.index(".p2align 6")
-        ins[at:at] = ["v_mov_b32 v%d, 0x%08x" % (S_KW_V, S_K_WIDE), "v_mov_b32 v%d, 0x%08x" % (S_KN_V, S_K_NARROW), "v_mov_b32 v%d, 1.0" % S_ONE_V]
-    stubs = []
-    for site in range(GROUP):
-        stubs += strict_stub(site, site)
-    return ins + ["s_branch 60f"] + stubs + ["60:"]
-
-
-
 BX, BY, BZ = "v15", "v16", "v17"        # level-2 accumulators (finished blocks)
 TOT, BLK, FULL = 70, 71, 72             # groups still to do after this block, groups per block, "this block is a full one"
 HEAD_BYTES = 16                         # the four 4-byte scalar instructions between the label `2:` and the loop head
@@ -356,7 +240,7 @@ def build(pad, m=SHORT, stagger=False, diag=None, style="fmaak"):
     px, py, pz = DSETS[1]
     nb = m["bodies"]
     buf_bytes = 16 * nb
-    if style in ("fmaak", "strict") and not diag and m is SHORT:
+    if style == "fmaak" and not diag and m is SHORT:
         # the product loop reads eps as a literal, so EPS's SGPR (s33) is free inside the loop: the "full block" flag lives there
         # and the loop's highest scalar is s71 (with a workgroup of 16 waves hipcc is told to fit 8 waves per SIMD and then
         # treats s72 as reserved)
@@ -398,10 +282,6 @@ def build(pad, m=SHORT, stagger=False, diag=None, style="fmaak"):
         ins += ["s_nop 0", "s_nop 0"] * (nb // 4)
         for b in range(nb):
             ins += diag_body(diag, b, m["a"], b)
-    elif style == "strict":
-        ins += loads(m, m["b"], buf_bytes)
-        for b in range(nb):
-            ins += body_strict(b, m["a"], b, b)
     else:
         ins += loads(m, m["b"], buf_bytes)
         for b in range(nb):
@@ -419,10 +299,6 @@ def build(pad, m=SHORT, stagger=False, diag=None, style="fmaak"):
         ins += ["s_nop 0", "s_nop 0"] * (nb // 4)
         for b in range(nb):
             ins += diag_body(diag, nb + b, m["b"], b)
-    elif style == "strict":
-        ins += loads(m, m["a"], 0)
-        for b in range(nb):
-            ins += body_strict(nb + b, m["b"], b, nb + b)
     else:
         ins += loads(m, m["a"], 0)
         for b in range(nb):
@@ -571,7 +447,7 @@ def check(ins, strict=True):
         op = i.split()[0]
         size = 4 if (op.startswith("s_") and not op.startswith("s_load")) or op.endswith("_e32") else 8
         if op.startswith("v_"):
-            assert op.endswith("_e64") or op.endswith("_e32") or op in ("v_fma_f32", "v_pk_add_f32", "v_fmaak_f32", "v_fmamk_f32", "v_sub_f32_sdwa"), i
+            assert op.endswith("_e64") or op.endswith("_e32") or op in ("v_fma_f32", "v_pk_add_f32", "v_fmaak_f32", "v_sub_f32_sdwa"), i
             regs = [int(x) for x in re.findall(r"\bv(\d+)\b", i)]
             regs = regs if op.startswith("v_fmac") else regs[1:]                     # fmac reads its destination
             if len(regs) == 3:
@@ -598,23 +474,12 @@ def main():
             assert (head, phase) == ((56, 0) if v == 0 else (60, 4)), (head, phase)   # the placement round 1 measured
             f.write("#define NB_FORCE_LOOP_V%d \"%s\"\n" % (v, "\\n\\t".join(ins)))
         f.write("#define NB_FORCE_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
-        # the strict arithmetic in the product loop's structure and placement (NBODY_ARITH_STRICT; body_strict above)
-        ins = build_strict(15 - HEAD_BYTES // 4)
-        assert check(ins) == (60, 4)
-        f.write("#define NB_FORCE_LOOP_STRICT \"%s\"\n" % "\\n\\t".join(ins))
-        sregs_strict = sorted(set([S_Y, S_HI, S_LO, S_E, S_R, S_R2, S_A, S_B, S_C, S_C + 1, S_KW_V, S_KN_V, S_ONE_V] + [r + h for r in (S_D0, S_D1, S_D2, S_D3, S_D4) for h in (0, 1)]))
-        f.write("#define NB_FORCE_LOOP_STRICT_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob[:-2] + ["v%d" % r for r in sregs_strict] + ["vcc", "scc", "memory"]))
         f.write("#define NB_FORCE_LOOP_DIAG_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob_diag))
         f.write("#define NB_FORCE_LOOP_GROUP %d\n" % GROUP)
         # Everything below up to NB_FORCE_LOOP_LONG exists only in the diagnostic build (`make diag`, -DNBODY_DIAG_LOOPS ->
         # libnbody_hip_diag.so): experiment encodings of the same operations (bit-identical, slower) and TIMING-ONLY forms
         # with wrong results.  The product library holds V0, V1 and LONG only and refuses the other NBODY_OPT_ISA_PHASE values.
         f.write("#ifdef NBODY_DIAG_LOOPS\n")
-        # TIMING-ONLY forms of the strict loop (wrong for the ~2^-16 of pairs that need the IEEE form): what the compare and the branch cost
-        for form in (1, 2, 3, 4, 5):
-            ins = build_strict(15 - HEAD_BYTES // 4, form)
-            check(ins, strict=(form != 3))
-            f.write("#define NB_FORCE_LOOP_STRICT_D%d \"%s\"\n" % (form, "\\n\\t".join(ins)))
         ins = build(15 - HEAD_BYTES // 4, SHORT, stagger=True)
         assert check(ins) == (60, 4)
         f.write("#define NB_FORCE_LOOP_V2 \"%s\"\n" % "\\n\\t".join(ins))
