@@ -54,3 +54,17 @@ def test_every_profile_of_the_current_round_is_indexed():
         if not (f in index or stem in index or (f.startswith("pmc_") and "pmc_*.json" in index)):
             missing.append(f)
     assert not missing, missing
+
+
+def test_design_prose_stays_within_120_columns():
+    """VERDICT r04 housekeeping: DESIGN.md's prose is wrapped at 120 columns (tables, headings and code fences cannot be);
+    `python tools/wrap_md.py DESIGN.md` re-flows it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wrap_md", os.path.join(ROOT, "tools", "wrap_md.py"))
+    wm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wm)
+    for doc in ("DESIGN.md", os.path.join("profiles", "README.md")):
+        src = open(os.path.join(ROOT, doc)).read()
+        assert wm.too_long(src, 120) == [], doc
+        if doc == "DESIGN.md":
+            assert wm.wrap(src, 120) == src          # re-flowing it changes nothing: it IS the tool's output

@@ -96,7 +96,9 @@ def test_inverse_cube_of_the_timed_fp64_arithmetic_over_the_whole_range_of_d2(nb
     by the N = 64 fixture's 8-ulp bound.  Here per PAIR, over d2 from the softening (1e-9) to 1e12 with random significands: a two-body
     system at separation d along a random direction gives F_0 = d * inv3(d2) (the self term adds 0), so the timed arithmetic and the
     strict one (IEEE square root and divide, then inv * (inv * inv): the oracle's expression) must agree to a few ulps of the largest
-    component — <= 4: the strict chain's own five roundings are the larger part of that."""
+    component.  The strict chain's own roundings are the larger part of the allowance: inv carries two (<= 2 x 2^-53), its cube three
+    times that plus two more, the product with d another — up to 9 x 2^-53 relative against < 3 x 2^-53 for the timed form, i.e. up to
+    12 half-ulps = 6-12 ulps of the result depending on where its significand lies.  Measured worst: 6.0; bound 8."""
     rng = np.random.default_rng(5)
     m = 3000
     mag = 10.0 ** rng.uniform(-6.0, 6.0, m)
@@ -121,4 +123,4 @@ def test_inverse_cube_of_the_timed_fp64_arithmetic_over_the_whole_range_of_d2(nb
         worst = float((np.abs(a - b).max(axis=1) / ulp).max())
     with capsys.disabled():
         print("\n[fp64 inverse cube] %d pairs, d2 in [1e-12, 4e12]: timed arithmetic vs IEEE chain, worst %.2f ulp of the pair's largest component" % (m, worst))
-    assert worst <= 4.0
+    assert worst <= 8.0
