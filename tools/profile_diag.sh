@@ -12,7 +12,7 @@ out=gpurun_out/prof_diag
 mkdir -p $out
 export TMPDIR=/tmp
 for ph in $PHASES; do
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out/ph$ph -- python3 bench.py --in-process --configs-pass never --no-cpu-baseline --steps 3 --isa-phase $ph > $out/bench_ph$ph.json 2> $out/ph$ph.err
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out/ph$ph -- python3 bench.py --in-process --configs-pass never --strict-pass never --no-cpu-baseline --steps 3 --isa-phase $ph > $out/bench_ph$ph.json 2> $out/ph$ph.err
   echo "phase $ph rc=$?"
 done
 python3 - <<'PY'
