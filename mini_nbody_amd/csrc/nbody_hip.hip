@@ -309,19 +309,33 @@ int alloc_local(Local& L) {
   return NBODY_OK;
 }
 
-int ensure_partial(Local& L) {
-  const size_t need = (size_t)g.nseg * part_stride(L.n_local);
-  if (L.partial && need <= L.partial_words) return NBODY_OK;
-  HIPC(hipSetDevice(L.device));
-  if (L.partial) { HIPC(hipFree(L.partial)); L.partial = nullptr; L.partial_words = 0; }
-  HIPC(hipMalloc(&L.partial, (need + 64) * word_bytes()));
-  L.partial_words = need;
-  return NBODY_OK;
+// A mailbox request is two or three launches with fixed arguments for a given NUM_PTS: the second request of a size captures them into a
+// HIP graph (the first runs eagerly: a graph captured before its kernels have ever run replays slower for good, see step_impl), later
+// ones replay it — one submission instead of three.  A few sizes are kept (least recently used goes); anything that changes what the
+// launches would be (an option, the current position buffer, a new context) drops them all.
+struct MailboxGraph { int n = 0, cur = -1; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
+constexpr int kMailboxGraphs = 8;
+MailboxGraph g_mb_graph[kMailboxGraphs];
+unsigned long long g_mb_clock = 0;
+void drop_mailbox_graphs() {
+  for (MailboxGraph& m : g_mb_graph) { if (m.exec) (void)hipGraphExecDestroy(m.exec); m = MailboxGraph(); }
 }
 
 void drop_step_graph() {
   if (g.step_graph) { (void)hipGraphExecDestroy(g.step_graph); g.step_graph = nullptr; }
   g.graph_cur = -1;
+  drop_mailbox_graphs();
+}
+
+int ensure_partial(Local& L) {
+  const size_t need = (size_t)g.nseg * part_stride(L.n_local);
+  if (L.partial && need <= L.partial_words) return NBODY_OK;
+  HIPC(hipSetDevice(L.device));
+  drop_step_graph();   // captured launches hold the old buffer's address (a mailbox request of another size may be what grows it)
+  if (L.partial) { HIPC(hipFree(L.partial)); L.partial = nullptr; L.partial_words = 0; }
+  HIPC(hipMalloc(&L.partial, (need + 64) * word_bytes()));
+  L.partial_words = need;
+  return NBODY_OK;
 }
 
 int reconfigure() {
@@ -1191,6 +1205,22 @@ int wait_stream(hipStream_t stream) {
   return NBODY_OK;
 }
 
+// the launches of one request on the compute stream: RAM A's read port, the force pass storing into RAM B (and its combine)
+int mailbox_launches(Local& L, int num_pts) {
+  // bodies are words 1..N                                              S/top_level.vhd:55, 206-208
+  hipLaunchKernelGGL(ingest_kernel, dim3((num_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, L.compute,
+                     (f4*)L.pos[L.cur], (const f4*)((const char*)g.mb_a_dev + 16), num_pts);
+  HIPC(hipGetLastError());
+  // RAM B's write port: the force launch (or its combine) stores {Fx, Fy, Fz, 0} of body k at word k-1 itself, words >= N are never
+  // written                                                             S/compute_store.vhd:213, 227-242
+  const Finish fin = {false, false, true};
+  L.force_dst = g.mb_b_dev;
+  int rc = launch_force(L, 0, num_pts, g.nslices - 1, g.nslices, fin, 0.f, 0.0);
+  if (!rc) rc = launch_combine(L, 0, num_pts, fin, 0.f, 0.0);
+  L.force_dst = nullptr;
+  return rc;
+}
+
 int mailbox_request(const void* ram_a, void* ram_b, int num_pts) {
   Local& L = g.loc[0];
   HIPC(hipSetDevice(L.device));
@@ -1199,19 +1229,41 @@ int mailbox_request(const void* ram_a, void* ram_b, int num_pts) {
   NBC(scope.enter(num_pts));
   // RAM A: the library's own pinned image is read in place; any other host buffer is copied into it first
   if (ram_a != g.mb_a) memcpy((char*)g.mb_a + 16, (const char*)ram_a + 16, (size_t)num_pts * 16);
-  // bodies are words 1..N                                              S/top_level.vhd:55, 206-208
-  hipLaunchKernelGGL(ingest_kernel, dim3((num_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, L.compute,
-                     (f4*)L.pos[L.cur], (const f4*)((const char*)g.mb_a_dev + 16), num_pts);
-  HIPC(hipGetLastError());
   L.all_present = true;
-  // RAM B's write port: the force launch (or its combine) stores {Fx, Fy, Fz, 0} of body k at word k-1 itself, words >= N are never
-  // written                                                             S/compute_store.vhd:213, 227-242
-  const Finish fin = {false, false, true};
-  L.force_dst = g.mb_b_dev;
-  int rc = launch_force(L, 0, num_pts, g.nslices - 1, g.nslices, fin, 0.f, 0.0);
-  if (!rc) rc = launch_combine(L, 0, num_pts, fin, 0.f, 0.0);
-  L.force_dst = nullptr;
-  if (rc) { g.tickets_dirty = true; return rc; }
+  static const bool graphs_on = !(getenv("NBODY_MAILBOX_GRAPH") && atoi(getenv("NBODY_MAILBOX_GRAPH")) == 0);
+  MailboxGraph* slot = nullptr;
+  if (graphs_on && g.opt.graph && !g.opt.timing) {
+    MailboxGraph* lru = &g_mb_graph[0];
+    for (MailboxGraph& m : g_mb_graph) {
+      if (m.n == num_pts && m.cur == L.cur) { slot = &m; break; }
+      if (m.used < lru->used) lru = &m;
+    }
+    if (!slot) {   // first request of this size: remembered, launched eagerly
+      if (lru->exec) (void)hipGraphExecDestroy(lru->exec);
+      *lru = MailboxGraph();
+      lru->n = num_pts; lru->cur = L.cur; lru->used = ++g_mb_clock;
+    } else {
+      slot->used = ++g_mb_clock;
+      if (!slot->exec) {   // second request of this size: capture
+        hipGraph_t graph = nullptr;
+        HIPC(hipStreamBeginCapture(L.compute, hipStreamCaptureModeThreadLocal));
+        const int rc = mailbox_launches(L, num_pts);
+        const hipError_t e = hipStreamEndCapture(L.compute, &graph);
+        g.tickets_dirty = false;   // capturing executes nothing
+        if (rc || e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); if (rc) return rc; g_last_line = __LINE__; return (int)e; }
+        const hipError_t ie = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { slot->exec = nullptr; g_last_line = __LINE__; return (int)ie; }
+      }
+    }
+  }
+  if (slot && slot->exec) {
+    const hipError_t e = hipGraphLaunch(slot->exec, L.compute);
+    if (e != hipSuccess) { g.tickets_dirty = true; g_last_line = __LINE__; return (int)e; }
+  } else {
+    const int rc = mailbox_launches(L, num_pts);
+    if (rc) { g.tickets_dirty = true; return rc; }
+  }
   NBC(wait_stream(L.compute));
   if (ram_b != g.mb_b) memcpy(ram_b, g.mb_b, (size_t)num_pts * 16);
   return NBODY_OK;

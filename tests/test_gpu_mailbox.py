@@ -202,3 +202,36 @@ def test_strict_arithmetic_is_refused_on_a_device_that_fails_the_proof(nb):
     assert lines[4:] == ["fp64 strict: granted", "plain mailbox: granted"], lines
     # and on the real device the proof holds
     assert nb.strict_proof() == (0, 0)
+
+
+def test_repeated_requests_replay_a_captured_graph_and_stay_bit_exact(nb, oracle_fast):
+    """A size's second request captures its launches into a HIP graph, later ones replay it; eight sizes are kept, the least recently used
+    goes.  Every answer must be the first answer: sizes repeated, alternated, evicted and re-captured, in both arithmetics, and inside
+    an nbody_init context whose position buffer toggles with every step (the captured launches hold its address)."""
+    pos_all, _ = nb.make_bodies(4096, seed=31)
+    sizes = [9, 100, 40, 777, 1024, 63, 65, 2085, 4096, 300, 1, 2]          # 12 > the 8 graphs kept
+    for faithful in (True, False):
+        with nb.Mailbox(capacity=4096, faithful=faithful) as mb:
+            first = {}
+            for rnd in range(4):
+                for n in (sizes if rnd % 2 == 0 else sizes[::-1]):
+                    got = mb.forces(pos_all[:n])
+                    if n not in first:
+                        first[n] = got
+                        if faithful and n <= 1024:
+                            assert np.array_equal(bits(got), bits(rtl_oracle(oracle_fast, pos_all[:n], pos_all[:n]))), n
+                    assert np.array_equal(bits(got), bits(first[n])), (faithful, rnd, n)
+            for _ in range(5):                                             # the steady state of a PS driver: one size, again and again
+                assert np.array_equal(bits(mb.forces(pos_all[:777])), bits(first[777]))
+    pos, vel = nb.make_bodies(1000, seed=5)
+    with nb.NBody(1000) as eng:
+        eng.upload(pos, vel)
+        want = None
+        for k in range(6):
+            out = nb.mailbox.run(eng, nb.mailbox.encode_request(pos_all[:300]))
+            want = out if want is None else want
+            assert np.array_equal(bits(out), bits(want)), k
+            if k % 2 == 1:
+                eng.upload(pos, vel)
+                eng.step(0.01, 1)                                          # the current position buffer toggles
+                eng.sync()
