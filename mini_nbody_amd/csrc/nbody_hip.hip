@@ -309,22 +309,9 @@ int alloc_local(Local& L) {
   return NBODY_OK;
 }
 
-// A mailbox request is two or three launches with fixed arguments for a given NUM_PTS: the second request of a size captures them into a
-// HIP graph (the first runs eagerly: a graph captured before its kernels have ever run replays slower for good, see step_impl), later
-// ones replay it — one submission instead of three.  A few sizes are kept (least recently used goes); anything that changes what the
-// launches would be (an option, the current position buffer, a new context) drops them all.
-struct MailboxGraph { int n = 0, cur = -1; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
-constexpr int kMailboxGraphs = 8;
-MailboxGraph g_mb_graph[kMailboxGraphs];
-unsigned long long g_mb_clock = 0;
-void drop_mailbox_graphs() {
-  for (MailboxGraph& m : g_mb_graph) { if (m.exec) (void)hipGraphExecDestroy(m.exec); m = MailboxGraph(); }
-}
-
 void drop_step_graph() {
   if (g.step_graph) { (void)hipGraphExecDestroy(g.step_graph); g.step_graph = nullptr; }
   g.graph_cur = -1;
-  drop_mailbox_graphs();
 }
 
 int ensure_partial(Local& L) {
@@ -1230,40 +1217,10 @@ int mailbox_request(const void* ram_a, void* ram_b, int num_pts) {
   // RAM A: the library's own pinned image is read in place; any other host buffer is copied into it first
   if (ram_a != g.mb_a) memcpy((char*)g.mb_a + 16, (const char*)ram_a + 16, (size_t)num_pts * 16);
   L.all_present = true;
-  static const bool graphs_on = !(getenv("NBODY_MAILBOX_GRAPH") && atoi(getenv("NBODY_MAILBOX_GRAPH")) == 0);
-  MailboxGraph* slot = nullptr;
-  if (graphs_on && g.opt.graph && !g.opt.timing) {
-    MailboxGraph* lru = &g_mb_graph[0];
-    for (MailboxGraph& m : g_mb_graph) {
-      if (m.n == num_pts && m.cur == L.cur) { slot = &m; break; }
-      if (m.used < lru->used) lru = &m;
-    }
-    if (!slot) {   // first request of this size: remembered, launched eagerly
-      if (lru->exec) (void)hipGraphExecDestroy(lru->exec);
-      *lru = MailboxGraph();
-      lru->n = num_pts; lru->cur = L.cur; lru->used = ++g_mb_clock;
-    } else {
-      slot->used = ++g_mb_clock;
-      if (!slot->exec) {   // second request of this size: capture
-        hipGraph_t graph = nullptr;
-        HIPC(hipStreamBeginCapture(L.compute, hipStreamCaptureModeThreadLocal));
-        const int rc = mailbox_launches(L, num_pts);
-        const hipError_t e = hipStreamEndCapture(L.compute, &graph);
-        g.tickets_dirty = false;   // capturing executes nothing
-        if (rc || e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); if (rc) return rc; g_last_line = __LINE__; return (int)e; }
-        const hipError_t ie = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) { slot->exec = nullptr; g_last_line = __LINE__; return (int)ie; }
-      }
-    }
-  }
-  if (slot && slot->exec) {
-    const hipError_t e = hipGraphLaunch(slot->exec, L.compute);
-    if (e != hipSuccess) { g.tickets_dirty = true; g_last_line = __LINE__; return (int)e; }
-  } else {
-    const int rc = mailbox_launches(L, num_pts);
-    if (rc) { g.tickets_dirty = true; return rc; }
-  }
+  // (replaying the request's launches from a captured HIP graph was measured in round 5 and not kept: 21.1 against 23.7 us at N = 9,
+  //  29.8 against 30.1 at N = 1024, level above — gpurun_out/r05/mailbox_rate_b*.txt)
+  const int rc = mailbox_launches(L, num_pts);
+  if (rc) { g.tickets_dirty = true; return rc; }
   NBC(wait_stream(L.compute));
   if (ram_b != g.mb_b) memcpy(ram_b, g.mb_b, (size_t)num_pts * 16);
   return NBODY_OK;

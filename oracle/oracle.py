@@ -79,6 +79,16 @@ class Oracle:
         L.ref_num_threads.restype = C.c_int
         L.ref_set_num_threads.argtypes = [C.c_int]
 
+        self._max_threads = None      # the thread count this object may use at most (None: whatever OpenMP would take)
+
+    def _size_team(self, pairs):
+        """Size the OpenMP team to the work of the next call: a pass over a few thousand pairs on a 256-thread host spends ~0.1 s waking
+        its team and microseconds computing (the GPU suite makes thousands of such calls).  One thread per 250 000 pairs, at most the
+        host's (or set_num_threads()'s) count.  The result does not depend on the team: rows are independent."""
+        if self._max_threads is None:
+            self._max_threads = max(1, self.lib.ref_num_threads())
+        self.lib.ref_set_num_threads(int(max(1, min(self._max_threads, pairs // 250000))))
+
     # ---- stages ----
     def soft(self):
         return np.float32(self.lib.ref_soft())
@@ -121,6 +131,7 @@ class Oracle:
             ptr = acc_in.ctypes.data_as(C.c_void_p)
         else:
             ptr = None
+        self._size_team(len(rows) * len(src))
         self.lib.ref_forces_f32(rows, len(rows), src, len(src), ptr, acc, d2, rsqrt, summ)
         return acc
 
@@ -130,11 +141,13 @@ class Oracle:
         src = rows if src is None else np.ascontiguousarray(src, np.float32).reshape(-1, 4)
         o = order_ if order_ is not None else order(**kw)
         acc = np.zeros_like(rows)
+        self._size_team(len(rows) * len(src))
         self.lib.ref_forces_f32_order(rows, len(rows), src, len(src), acc, C.byref(o))
         return acc
 
     def step_order(self, pos, vel, dt, nsteps, order_=None, **kw):
         o = order_ if order_ is not None else order(**kw)
+        self._size_team(len(pos) * len(pos))
         self.lib.ref_step_f32_order(pos, vel, dt, len(pos), nsteps, C.byref(o))
 
     def forces_f64_order(self, rows, src=None, order_=None, **kw):
@@ -143,11 +156,13 @@ class Oracle:
         src = rows if src is None else np.ascontiguousarray(src, np.float64).reshape(-1, 4)
         o = order_ if order_ is not None else order(**kw)
         acc = np.zeros_like(rows)
+        self._size_team(len(rows) * len(src))
         self.lib.ref_forces_f64_order(rows, len(rows), src, len(src), acc, C.byref(o))
         return acc
 
     def step_f64_order(self, pos, vel, dt, nsteps, order_=None, **kw):
         o = order_ if order_ is not None else order(**kw)
+        self._size_team(len(pos) * len(pos))
         self.lib.ref_step_f64_order(pos, vel, dt, len(pos), nsteps, C.byref(o))
 
     def segment_bounds(self, q, t, n, nslices, sub):
@@ -159,6 +174,7 @@ class Oracle:
         rows = np.ascontiguousarray(rows, np.float64).reshape(-1, 4)
         src = rows if src is None else np.ascontiguousarray(src, np.float64).reshape(-1, 4)
         acc = np.zeros_like(rows)
+        self._size_team(len(rows) * len(src))
         self.lib.ref_forces_f64(rows, len(rows), src, len(src), acc)
         return acc
 
@@ -166,11 +182,13 @@ class Oracle:
         rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 4)
         src = rows if src is None else np.ascontiguousarray(src, np.float32).reshape(-1, 4)
         acc = np.zeros(rows.shape, np.float64)
+        self._size_team(len(rows) * len(src))
         self.lib.ref_forces_f64_from_f32(rows, len(rows), src, len(src), acc)
         return acc
 
     def bodyForce(self, pos, vel, dt, d2=D2_FMA3, rsqrt=RSQRT_F64, summ=SUM_SEQ):
         """In place on vel (float32 or float64 arrays, n x 4)."""
+        self._size_team(len(pos) * len(pos))
         if pos.dtype == np.float64:
             self.lib.ref_bodyForce_f64(pos, vel, dt, len(pos))
         else:
@@ -183,6 +201,7 @@ class Oracle:
             self.lib.ref_integrate_f32(pos, vel, dt, len(pos))
 
     def step(self, pos, vel, dt, nsteps, d2=D2_FMA3, rsqrt=RSQRT_F64, summ=SUM_SEQ):
+        self._size_team(len(pos) * len(pos))
         if pos.dtype == np.float64:
             self.lib.ref_step_f64(pos, vel, dt, len(pos), nsteps)
         else:
@@ -196,7 +215,11 @@ class Oracle:
         return pos, vel
 
     def num_threads(self):
-        return self.lib.ref_num_threads()
+        """the most threads a call of this object will use"""
+        if self._max_threads is None:
+            self._max_threads = max(1, self.lib.ref_num_threads())
+        return self._max_threads
 
     def set_num_threads(self, t):
-        self.lib.ref_set_num_threads(t)
+        self._max_threads = max(1, int(t))
+        self.lib.ref_set_num_threads(self._max_threads)

@@ -204,12 +204,11 @@ def test_strict_arithmetic_is_refused_on_a_device_that_fails_the_proof(nb):
     assert nb.strict_proof() == (0, 0)
 
 
-def test_repeated_requests_replay_a_captured_graph_and_stay_bit_exact(nb, oracle_fast):
-    """A size's second request captures its launches into a HIP graph, later ones replay it; eight sizes are kept, the least recently used
-    goes.  Every answer must be the first answer: sizes repeated, alternated, evicted and re-captured, in both arithmetics, and inside
-    an nbody_init context whose position buffer toggles with every step (the captured launches hold its address)."""
+def test_repeated_and_alternating_requests_stay_bit_exact(nb, oracle_fast):
+    """The steady state of a PS driver: the same sizes again and again, in any order.  Every answer must be the first answer — twelve sizes
+    repeated and alternated in both arithmetics, and inside an nbody_init context whose position buffer toggles with every step."""
     pos_all, _ = nb.make_bodies(4096, seed=31)
-    sizes = [9, 100, 40, 777, 1024, 63, 65, 2085, 4096, 300, 1, 2]          # 12 > the 8 graphs kept
+    sizes = [9, 100, 40, 777, 1024, 63, 65, 2085, 4096, 300, 1, 2]
     for faithful in (True, False):
         with nb.Mailbox(capacity=4096, faithful=faithful) as mb:
             first = {}
