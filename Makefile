@@ -13,14 +13,14 @@ all: lib host oracle microbench
 
 lib: $(PKG)/libnbody_hip.so
 $(PKG)/libnbody_hip.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/force_loop_gfx950.inc include/nbody.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/nbody_hip.hip -ldl
+	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/nbody_hip.hip -ldl
 
 # The diagnostic library: the same source with -DNBODY_DIAG_LOOPS — the experiment encodings of the hand-scheduled loop and its
 # TIMING-ONLY forms (wrong results) that profiles/r02_loop_diagnostics.md was measured with.  Not part of `all`, never loaded by
 # the package unless NBODY_LIB points at it (tools/profile_diag.sh does).
 diag: $(PKG)/libnbody_hip_diag.so
 $(PKG)/libnbody_hip_diag.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/force_loop_gfx950.inc include/nbody.h
-	$(HIPCC) $(HIPFLAGS) -DNBODY_DIAG_LOOPS -shared -o $@ $(CSRC)/nbody_hip.hip -ldl
+	$(HIPCC) $(HIPFLAGS) -DNBODY_DIAG_LOOPS -shared -pthread -o $@ $(CSRC)/nbody_hip.hip -ldl
 
 # C host program (north_star: "host code stays in C"): links only the C-ABI
 host: build/nbody

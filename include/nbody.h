@@ -133,7 +133,9 @@ enum { NBODY_INFO_N = 1, NBODY_INFO_N_LOCAL, NBODY_INFO_FIRST_BODY, NBODY_INFO_R
        NBODY_INFO_XCD_MAP /* option value, -1 = auto */, NBODY_INFO_FUSE_COMBINE /* resolved: 1 = in-launch combine */,
        NBODY_INFO_COMM_FORM /* resolved NBODY_COMM_* of a multi-rank context, -1 with one rank */,
        NBODY_INFO_COMM_PRIORITY /* HIP priority of the transfer stream (0 = default priority) */,
-       NBODY_INFO_DIAG_BUILD /* 1: this is libnbody_hip_diag.so (timing-only loop forms present) */ };
+       NBODY_INFO_DIAG_BUILD /* 1: this is libnbody_hip_diag.so (timing-only loop forms present) */,
+       NBODY_INFO_MAILBOX_SERVED /* requests the mailbox's service thread has completed in this process */,
+       NBODY_INFO_MAILBOX_SERVING /* 1: nbody_mailbox_serve(1, .) is in effect */ };
 
 /* ---- lifetime ----
  * Replaces: power-up of the PL design + the ps_pl RAM allocation (S/top_level.vhd:100-117, 148-163). */
@@ -252,10 +254,20 @@ int nbody_forces_rows_d(int first_row, int n_rows, double *force_words);
  *   count them.  Returns NBODY_ERR_STATE if BEGIN is not set (the FSM stays in `waiting`: nothing read, nothing written),
  *   NBODY_ERR_ARG if NUM_PTS exceeds the capacity (the RTL has no such case: its RAM always holds 32767 bodies).
  *   The context's N, options, uploaded state's size and step graph are as before on return (its position buffer is overwritten, as by
- *   nbody_forces).  A context over several devices or ranks keeps its fixed N (NUM_PTS must equal it). */
+ *   nbody_forces).  A context over several devices or ranks keeps its fixed N (NUM_PTS must equal it).
+ * nbody_mailbox_serve(on, clock_khz): the mailbox WITHOUT a call per request.  on = 1: a library thread takes the place of the PL block's
+ *   FSM — it samples word 0 of the context's own RAM A (nbody_mailbox_rams) as the RTL does every clock (S/top_level.vhd:180-186), runs
+ *   each request it finds exactly as nbody_mailbox_run would, and rewrites word 0 (ticks in bits 63:32, BEGIN cleared LAST, so whoever
+ *   reads BEGIN = 0 also reads the ticks and RAM B).  The driver then only writes memory — bodies, then word 0 with NUM_PTS and BEGIN —
+ *   and polls word 0, as the PS does.  A request the library cannot take (NUM_PTS beyond the capacity, a device error) completes with
+ *   ticks = 0 and the error code in bits 127:96 of word 0, which the RTL always writes as 0.  While serving, the calling thread must
+ *   leave the context alone (nbody_mailbox_run answers NBODY_ERR_STATE; nbody_get_info is safe; NBODY_INFO_MAILBOX_SERVED counts
+ *   completed requests); on = 0 (and nbody_shutdown) stops and joins the thread.  The idle thread backs off from spinning to 50-us naps
+ *   after ~0.1 s without a request.  One-GPU fp32 contexts only. */
 int nbody_mailbox_open(int capacity, int faithful);
 int nbody_mailbox_rams(void **ram_a, void **ram_b, int *capacity);
 int nbody_mailbox_run(void *ram_a, void *ram_b, int clock_khz);
+int nbody_mailbox_serve(int on, int clock_khz);
 
 /* Multi-process transport without RCCL: call nbody_init_rank(..., uid128 = NULL), then register a function that
  * all-gathers a host array in place: on entry host_words[first..first+count) of this rank are valid (words of word_bytes

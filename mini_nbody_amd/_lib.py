@@ -20,7 +20,7 @@ COMM_RING, COMM_ALLGATHER, COMM_AUTO, COMM_DIRECT = 0, 1, 2, 3
 (INFO_N, INFO_N_LOCAL, INFO_FIRST_BODY, INFO_RANK, INFO_NRANKS, INFO_VARIANT, INFO_IBLOCK, INFO_JSUB, INFO_NSEG,
  INFO_DEVICE, INFO_CU_COUNT, INFO_CLOCK_KHZ, INFO_FP64, INFO_TILE, INFO_STEPS_DONE, INFO_SUM_ORDER, INFO_SUM_BLOCK,
  INFO_LAUNCHES_PER_STEP, INFO_HAS_COMM, INFO_WSPLIT, INFO_ISA_PHASE, INFO_LONG_BUFFERS, INFO_XCD_MAP, INFO_FUSE_COMBINE,
- INFO_COMM_FORM, INFO_COMM_PRIORITY, INFO_DIAG_BUILD) = range(1, 28)
+ INFO_COMM_FORM, INFO_COMM_PRIORITY, INFO_DIAG_BUILD, INFO_MAILBOX_SERVED, INFO_MAILBOX_SERVING) = range(1, 30)
 
 ERR_NOT_INIT, ERR_ARG, ERR_NO_DEVICE, ERR_RCCL_LOAD, ERR_STATE, ERR_UNSUPPORTED = 1001, 1002, 1003, 1004, 1005, 1006
 
@@ -33,6 +33,7 @@ SYMBOLS = [
     "nbody_set_host_gather", "nbody_download_slice", "nbody_comm_selftest", "nbody_forces_rows_d",
     "nbody_comm_selftest_virtual", "nbody_comm_plan", "nbody_comm_probe", "nbody_comm_time",
     "nbody_rsqrt_selftest", "nbody_rsqrt_strict", "nbody_strict_proof", "nbody_mailbox_open", "nbody_mailbox_rams",
+    "nbody_mailbox_serve",
 ]
 
 
@@ -85,6 +86,7 @@ def load():
         "nbody_rsqrt_strict": [fp, fp, i, i],
         "nbody_strict_proof": [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)],
         "nbody_mailbox_open": [i, i], "nbody_mailbox_rams": [C.POINTER(vp), C.POINTER(vp), C.POINTER(i)],
+        "nbody_mailbox_serve": [i, i],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

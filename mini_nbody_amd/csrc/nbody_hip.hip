@@ -28,7 +28,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/nbody.h"
@@ -1226,6 +1228,67 @@ int mailbox_request(const void* ram_a, void* ram_b, int num_pts) {
   return NBODY_OK;
 }
 
+
+// One request from the RAM images (the body of nbody_mailbox_run and of the service thread).  `served`: an error has no return value to
+// travel in, so it is written into word 0 (bits 127:96, which the RTL always writes as 0) with BEGIN cleared.
+int mailbox_run_impl(void* ram_a, void* ram_b, int clock_khz, bool served) {
+  const auto t0 = std::chrono::steady_clock::now();
+  // word 0: bit 0 BEGIN, bits [46:32] NUM_PTS, sampled with every request        S/top_level.vhd:180-186
+  uint32_t* w0 = (uint32_t*)ram_a;
+  if (!(w0[0] & 1u)) return NBODY_ERR_STATE;   // the FSM stays in `waiting`: nothing is read, nothing is written
+  const int num_pts = (int)(w0[1] & 0x7FFFu);
+  int rc = NBODY_OK;
+  if (g.nranks == 1) {
+    if (num_pts > g.cap) rc = NBODY_ERR_ARG;   // (the RTL's RAM always holds 32767 bodies; a smaller capacity is this library's notion)
+    // NUM_PTS = 0: block_setup finds THIS_PTR > NUM_PTS at once and goes to `complete` (S/top_level.vhd:189-192): RAM B untouched
+    else if (num_pts > 0) rc = mailbox_request(ram_a, ram_b, num_pts);
+  } else {
+    // a context over several devices / ranks keeps its fixed N: every rank brings the same images (nbody_forces)
+    if (num_pts != g.n) rc = NBODY_ERR_ARG;
+    else rc = forces_impl((const float*)ram_a + 4, (float*)ram_b, num_pts);
+  }
+  if (rc && !served) return rc;
+  // completion: word 0 <- {ticks in [63:32], 0 elsewhere}: BEGIN reads 0          S/top_level.vhd:146, 255-263
+  // one tick = 1000 clocks (S/top_level.vhd:121-144); the counter goes to 1 on BEGIN's rising edge (:138-139); BEGIN-to-done as this
+  // host sees it (the device's reads of RAM A and writes of RAM B included)
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const double khz = clock_khz > 0 ? (double)clock_khz : 300000.0;
+  const uint32_t ticks = rc ? 0u : 1u + (uint32_t)(ms * khz / 1000.0);
+  w0[1] = ticks; w0[2] = 0; w0[3] = (uint32_t)rc;
+  __atomic_store_n(&w0[0], 0u, __ATOMIC_RELEASE);   // BEGIN is cleared LAST: whoever sees it cleared sees the ticks and RAM B
+  return rc;
+}
+
+// The PL block serves the PS without being called: its FSM samples word 0 of RAM A every clock (S/top_level.vhd:180-186).  The same on
+// a host: a library thread polls word 0 of the context's own RAM A, runs every request it finds and rewrites word 0 — the driver only
+// writes and reads memory.  Idle polling backs off: `pause` for the first ~ms, then yields, then 50-us naps after ~0.1 s without work.
+std::thread g_serve_thread;
+std::atomic<int> g_serve_on{0};
+std::atomic<long long> g_served{0};
+int g_serve_khz = 0;
+
+void serve_loop() {
+  uint32_t* w0 = (uint32_t*)g.mb_a;
+  unsigned idle = 0;
+  while (g_serve_on.load(std::memory_order_acquire)) {
+    if (!(__atomic_load_n(&w0[0], __ATOMIC_ACQUIRE) & 1u)) {
+      ++idle;
+      if (idle < 20000) __builtin_ia32_pause();
+      else if (idle < 400000) std::this_thread::yield();
+      else std::this_thread::sleep_for(std::chrono::microseconds(50));
+      continue;
+    }
+    idle = 0;
+    (void)mailbox_run_impl(g.mb_a, g.mb_b, g_serve_khz, true);
+    g_served.fetch_add(1, std::memory_order_relaxed);
+  }
+}
+
+void serve_stop() {
+  if (g_serve_on.exchange(0, std::memory_order_acq_rel) && g_serve_thread.joinable()) g_serve_thread.join();
+  else if (g_serve_thread.joinable()) g_serve_thread.join();
+}
+
 }  // namespace
 
 // ============================================================================
@@ -1608,6 +1671,7 @@ int nbody_rsqrt_strict(const float* x, float* y, int n, int ieee_only) {
 }
 
 void nbody_shutdown(void) {
+  serve_stop();   // the mailbox's service thread, if one runs, ends before anything it uses is freed
   drop_step_graph();
   for (int l = 0; l < kMaxLocal; ++l) free_local(g.loc[l]);
   if (g.host_stage) { (void)hipHostFree(g.host_stage); g.host_stage = nullptr; }
@@ -1687,6 +1751,8 @@ int nbody_get_info(int key, long long* value) {
     case NBODY_INFO_FUSE_COMBINE: *value = g.fuse; break;
     case NBODY_INFO_COMM_FORM: *value = g.nranks > 1 ? resolved_comm_form() : -1; break;
     case NBODY_INFO_COMM_PRIORITY: *value = g.comm_priority; break;
+    case NBODY_INFO_MAILBOX_SERVED: *value = g_served.load(std::memory_order_relaxed); break;
+    case NBODY_INFO_MAILBOX_SERVING: *value = g_serve_on.load(std::memory_order_acquire); break;
     case NBODY_INFO_DIAG_BUILD:
 #ifdef NBODY_DIAG_LOOPS
       *value = 1; break;
@@ -1787,27 +1853,20 @@ int nbody_mailbox_rams(void** ram_a, void** ram_b, int* capacity) {
 int nbody_mailbox_run(void* ram_a, void* ram_b, int clock_khz) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (g.fp64 || !ram_a || !ram_b) return NBODY_ERR_ARG;
-  const auto t0 = std::chrono::steady_clock::now();
-  // word 0: bit 0 BEGIN, bits [46:32] NUM_PTS, sampled with every request        S/top_level.vhd:180-186
-  uint32_t* w0 = (uint32_t*)ram_a;
-  if (!(w0[0] & 1u)) return NBODY_ERR_STATE;   // the FSM stays in `waiting`: nothing is read, nothing is written
-  const int num_pts = (int)(w0[1] & 0x7FFFu);
-  if (g.nranks == 1) {
-    if (num_pts > g.cap) return NBODY_ERR_ARG;   // (the RTL's RAM always holds 32767 bodies; a smaller capacity is this library's notion)
-    // NUM_PTS = 0: block_setup finds THIS_PTR > NUM_PTS at once and goes to `complete` (S/top_level.vhd:189-192): RAM B untouched
-    if (num_pts > 0) NBC(mailbox_request(ram_a, ram_b, num_pts));
-  } else {
-    // a context over several devices / ranks keeps its fixed N: every rank brings the same images (nbody_forces)
-    if (num_pts != g.n) return NBODY_ERR_ARG;
-    NBC(forces_impl((const float*)ram_a + 4, (float*)ram_b, num_pts));
-  }
-  // completion: word 0 <- {ticks in [63:32], 0 elsewhere}: BEGIN reads 0          S/top_level.vhd:146, 255-263
-  // one tick = 1000 clocks (S/top_level.vhd:121-144); the counter goes to 1 on BEGIN's rising edge (:138-139); BEGIN-to-done as this
-  // host sees it (the device's reads of RAM A and writes of RAM B included)
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  const double khz = clock_khz > 0 ? (double)clock_khz : 300000.0;
-  const uint32_t ticks = 1u + (uint32_t)(ms * khz / 1000.0);
-  w0[0] = 0; w0[1] = ticks; w0[2] = 0; w0[3] = 0;
+  if (g_serve_on.load(std::memory_order_acquire)) return NBODY_ERR_STATE;   // the service thread owns the mailbox: write BEGIN, poll word 0
+  return mailbox_run_impl(ram_a, ram_b, clock_khz, false);
+}
+
+int nbody_mailbox_serve(int on, int clock_khz) {
+  if (!on) { serve_stop(); return NBODY_OK; }
+  if (!g.init) return NBODY_ERR_NOT_INIT;
+  if (g.fp64 || g.nranks != 1) return NBODY_ERR_UNSUPPORTED;
+  if (g_serve_on.load(std::memory_order_acquire)) { g_serve_khz = clock_khz; return NBODY_OK; }
+  NBC(mailbox_rams());
+  NBC(sync_all());
+  g_serve_khz = clock_khz;
+  g_serve_on.store(1, std::memory_order_release);
+  g_serve_thread = std::thread(serve_loop);
   return NBODY_OK;
 }
 

@@ -86,6 +86,31 @@ class Mailbox:
         out, _ = self.run(clock_khz)
         return out.copy()
 
+    # ---- the mailbox without a call per request (nbody_mailbox_serve): a library thread plays the PL block's FSM ----
+    def serve(self, on=True, clock_khz=0):
+        """Start (or stop) the service thread: from then on a request is `post()` followed by polling word 0 — memory only."""
+        L.check(self.lib.nbody_mailbox_serve(1 if on else 0, int(clock_khz)))
+        self._serving = bool(on)
+
+    def wait(self, timeout=10.0):
+        """What the PS does after raising BEGIN: poll word 0 of RAM A until BEGIN reads 0.  Returns (RAM B words 0..N-1 (view), ticks);
+        raises if the library flagged the request (bits 127:96 of word 0, which the RTL always writes as 0)."""
+        import time
+        n = int(self.ram_a[0, 1] & 0x7FFF)
+        w0 = self.ram_a[0]
+        t0 = time.perf_counter()
+        while w0[0] & 1:
+            if time.perf_counter() - t0 > timeout:
+                raise TimeoutError("the mailbox did not complete within %.1f s" % timeout)
+        if int(w0[3]):
+            raise L.NBodyError(int(w0[3]), "mailbox request refused: " + self.lib.nbody_error_string(int(w0[3])).decode())
+        return self.ram_b[:n], int(w0[1])
+
+    def served(self):
+        v = C.c_longlong()
+        L.check(self.lib.nbody_get_info(L.INFO_MAILBOX_SERVED, C.byref(v)))
+        return v.value
+
     def close(self):
         if self._open:
             self.ram_a = self.ram_b = None

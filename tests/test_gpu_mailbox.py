@@ -234,3 +234,49 @@ def test_repeated_and_alternating_requests_stay_bit_exact(nb, oracle_fast):
                 eng.upload(pos, vel)
                 eng.step(0.01, 1)                                          # the current position buffer toggles
                 eng.sync()
+
+
+def test_served_mailbox_needs_no_call_per_request(nb, oracle_fast):
+    """nbody_mailbox_serve: a library thread plays the PL block's FSM (S/top_level.vhd:180-186, 255-263) — the driver writes the bodies,
+    then word 0 with NUM_PTS and BEGIN, and polls word 0 until BEGIN reads 0; nothing is called per request.  Same bits as the called
+    form, same protocol: RAM B untouched from word N on, NUM_PTS = 0 completes, a request the library cannot take comes back with its
+    error code in bits 127:96 of word 0 (where the RTL always writes 0) and BEGIN cleared."""
+    with nb.Mailbox(capacity=2048, faithful=True) as mb:
+        called = {n: mb.forces(fixture(n)[0]) for n in (9, 100, 40)}
+        before = mb.served()
+        mb.serve(True, clock_khz=300000)
+        try:
+            with pytest.raises(nb.NBodyError) as e:                # the service thread owns the mailbox now: the called form is refused
+                nb.mailbox.run(mb, nb.mailbox.encode_request(fixture(9)[0]))
+            assert e.value.code == nb._lib.ERR_STATE
+            count = 0
+            for rnd in range(3):
+                for n in (9, 100, 0, 40):
+                    mb.ram_b.view(np.uint32)[...] = SENTINEL
+                    mb.post(fixture(n)[0] if n else np.zeros((0, 4), np.float32))        # BEGIN is the last thing post() writes
+                    out, ticks = mb.wait()
+                    count += 1
+                    assert ticks >= 1 and np.all(mb.ram_a[0, [0, 2, 3]] == 0)
+                    assert np.all(mb.ram_b.view(np.uint32)[n:] == SENTINEL), n
+                    if n:
+                        assert np.array_equal(bits(out), bits(called[n])) and np.array_equal(bits(out), bits(fixture(n)[1])), n
+            big, _ = nb.make_bodies(2048, seed=3)
+            mb.post(big)
+            out, _ = mb.wait()
+            count += 1
+            assert np.array_equal(bits(out[:64]), bits(rtl_oracle(oracle_fast, big[:64], big)))
+            mb.ram_a[0] = (1, 2049, 0, 0)                          # beyond the capacity
+            with pytest.raises(nb.NBodyError) as e:
+                mb.wait()
+            count += 1
+            assert e.value.code == nb._lib.ERR_ARG and mb.ram_a[0, 0] == 0 and mb.ram_a[0, 1] == 0
+            assert mb.served() - before == count
+        finally:
+            mb.serve(False)
+        assert np.array_equal(bits(mb.forces(fixture(40)[0])), bits(called[40]))           # the called form works again
+    # shutdown with the thread still serving: it is stopped and joined first
+    mb = nb.Mailbox(capacity=64)
+    mb.serve(True)
+    mb.post(fixture(9)[0])
+    mb.wait()
+    mb.close()

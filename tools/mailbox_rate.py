@@ -4,6 +4,8 @@ arithmetic, in ONE context of the RTL's capacity that serves every size in turn 
   own RAMs     the context's pinned RAM A / RAM B (nbody_mailbox_rams): the device reads and writes them itself, no host copy;
                the time of the C call alone (BEGIN raised -> word 0 rewritten)
   any buffers  the caller's own (pageable) images: one host copy each way inside the call
+  served       nbody_mailbox_serve: no call at all — BEGIN written into the pinned RAM A, word 0 polled until BEGIN reads 0 (a library
+               thread plays the FSM); the time from the store of BEGIN to the load that sees it cleared, polled from Python
 and beside it what the RTL itself would take — N + ~250 clocks per 12 bodies (S/top_level.vhd:187-254) at the
 300 MHz the tick word is quoted at.
 usage (on the GPU box): python tools/mailbox_rate.py [--calls 200]"""
@@ -66,8 +68,19 @@ def main():
                     assert rc == 0, rc
                 us_any = per_call_us(anyb, args.calls)
                 assert np.array_equal(ram_b.view(np.uint32), mb.ram_b[:n].view(np.uint32))
-                print("N = %5d  %-44s own RAMs %8.1f us  any buffers %8.1f us  (%7.1f G pairs/s; ticks word %d)   RTL estimate %10.1f us = %6.0fx" %
-                      (n, name, us_own, us_any, float(n) * n / us_own / 1e3, ticks, rtl_us, rtl_us / us_own))
+                mb.serve(True, 300000)
+                w0 = mb.ram_a[0]
+
+                def served():
+                    w0[1] = n
+                    w0[0] = 1
+                    while w0[0] & 1:
+                        pass
+                us_srv = per_call_us(served, args.calls)
+                mb.serve(False)
+                assert np.array_equal(ram_b.view(np.uint32), mb.ram_b[:n].view(np.uint32)) and int(w0[3]) == 0
+                print("N = %5d  %-44s own RAMs %8.1f us  any buffers %8.1f us  served %8.1f us  (%7.1f G pairs/s; ticks word %d)   RTL estimate %10.1f us = %6.0fx" %
+                      (n, name, us_own, us_any, us_srv, float(n) * n / us_own / 1e3, ticks, rtl_us, rtl_us / us_own))
 
 
 if __name__ == "__main__":
