@@ -23,10 +23,15 @@ $(PKG)/libnbody_hip_diag.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(C
 	$(HIPCC) $(HIPFLAGS) -DNBODY_DIAG_LOOPS -shared -pthread -o $@ $(CSRC)/nbody_hip.hip -ldl
 
 # C host program (north_star: "host code stays in C"): links only the C-ABI
-host: build/nbody
+host: build/nbody build/mailbox_driver
 build/nbody: $(PKG)/host/nbody.c include/nbody.h include/nbody_ic.h $(PKG)/libnbody_hip.so
 	@mkdir -p build
 	$(CC) -std=c11 -O2 -Wall -Iinclude -o $@ $(PKG)/host/nbody.c -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,/opt/rocm/lib -lm
+
+# the PS-side driver of the reference's mailbox, plain C over the same C-ABI
+build/mailbox_driver: $(PKG)/host/mailbox_driver.c include/nbody.h include/nbody_ic.h $(PKG)/libnbody_hip.so
+	@mkdir -p build
+	$(CC) -std=c11 -O2 -Wall -Iinclude -o $@ $(PKG)/host/mailbox_driver.c -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,/opt/rocm/lib -lm
 
 oracle:
 	$(MAKE) -C oracle

@@ -17,14 +17,15 @@ def pytest_sessionstart(session):
     """Built artefacts are git-ignored; on a fresh checkout build them once (hipcc cross-compiles without a GPU).
     A failing build fails the session loudly: there is no fallback to test instead."""
     import subprocess
-    need = [os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"),
+    need = [os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so"), os.path.join(ROOT, "build", "nbody"), os.path.join(ROOT, "build", "mailbox_driver"),
             os.path.join(ROOT, "oracle", "libnbody_ref.so"), os.path.join(ROOT, "oracle", "libnbody_ref_fast.so"),
             os.path.join(ROOT, "oracle", "nbody_cpu"), os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip_diag.so")]
     # ... and again whenever a source is newer than what was built from it: a stale library must not be what the tests (or a gpurun
     # snapshot, which ships the built files) exercise
     src = [os.path.join(ROOT, "mini_nbody_amd", "csrc", f) for f in ("nbody_hip.hip", "nbody_kernels.hpp", "force_loop_gfx950.inc")] + \
           [os.path.join(ROOT, "include", "nbody.h"), os.path.join(ROOT, "oracle", "nbody_ref.c"), os.path.join(ROOT, "oracle", "nbody_ref.h"),
-           os.path.join(ROOT, "oracle", "nbody_cpu.c"), os.path.join(ROOT, "mini_nbody_amd", "host", "nbody.c")]
+           os.path.join(ROOT, "oracle", "nbody_cpu.c"), os.path.join(ROOT, "mini_nbody_amd", "host", "nbody.c"),
+           os.path.join(ROOT, "mini_nbody_amd", "host", "mailbox_driver.c")]
     if all(os.path.exists(p) for p in need) and max(os.path.getmtime(p) for p in src) <= min(os.path.getmtime(p) for p in need):
         return
     r = subprocess.run(["make", "lib", "diag", "host", "oracle"], cwd=ROOT, capture_output=True, text=True)

@@ -69,3 +69,41 @@ def test_fp64_host_program_and_cpu_program_print_the_same_checksum():
         a = subprocess.run([cpu, "4096", "6", "--fp64", "--segments", cfg.group(1), "--wsplit", cfg.group(2)], capture_output=True, text=True, timeout=300)
         assert a.returncode == 0, a.stderr
         assert line(a.stdout) == line(b.stdout), (extra, cfg.groups())
+
+
+_RTL_SUMS = {}
+
+
+@pytest.mark.parametrize("mode", [[], ["--served"], ["--timed"], ["--timed", "--served"]])
+def test_ps_side_mailbox_driver_in_c(nb, oracle_fast, mode):
+    """mini_nbody_amd/host/mailbox_driver.c — the PS-side driver INTEGRATION.md §1 shows, as a compiled C program over the C-ABI: ONE
+    power-up, then requests of several sizes incl. the RTL's maximum and an empty one, called (nbody_mailbox_run) or served (the driver
+    only writes RAM A and polls word 0).  Its force checksums must be the oracle's in the RTL-faithful mode (bit-exact forces, so the
+    double-precision sums agree to the last printed digit), within 1e-5 in the timed arithmetic; BEGIN cleared, ticks >= 1, RAM B
+    untouched from word N on."""
+    import oracle as O
+    exe = os.path.join(ROOT, "build", "mailbox_driver")
+    if not os.path.exists(exe):
+        pytest.fail("build/mailbox_driver is missing: run `make host`")
+    sizes = [9, 1000, 32767, 0, 40]
+    out = subprocess.run([exe] + mode + [str(n) for n in sizes], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("NUM_PTS")]
+    assert len(lines) == len(sizes), out.stdout
+    for n, line in zip(sizes, lines):
+        m = re.match(r"NUM_PTS (\d+)  BEGIN (\d)  ticks (\d+)  checksum \(sum of forces\): (\S+) (\S+) (\S+)  RAM B beyond word N-1 untouched: (\w+)", line)
+        assert m, line
+        assert int(m.group(1)) == n and m.group(2) == "0" and int(m.group(3)) >= 1 and m.group(7) == "yes", line
+        got = np.array([float(m.group(k)) for k in (4, 5, 6)])
+        if n == 0:
+            assert np.all(got == 0)
+            continue
+        if n not in _RTL_SUMS:                    # one oracle pass per size for the four modes
+            pos, _ = nb.make_bodies(n)
+            f = oracle_fast.forces_f32(pos, pos, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
+            _RTL_SUMS[n] = (f[:, :3].astype(np.float64).sum(0), np.abs(f[:, :3].astype(np.float64)).sum())
+        want, scale = _RTL_SUMS[n]
+        if "--timed" in mode:
+            assert np.abs(got - want).max() <= 1e-5 * scale, (n, got, want)
+        else:
+            assert np.allclose(got, want, rtol=0, atol=2e-9 * scale), (n, got, want)          # printed with %.9g
