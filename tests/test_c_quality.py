@@ -20,6 +20,15 @@ def test_header_is_strict_c99(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+@pytest.mark.parametrize("prog", ["nbody.c", "mailbox_driver.c"])
+def test_host_programs_are_warning_free_c11(prog):
+    """the two C host programs above the C-ABI (the north_star's bodyForce()/integrate() program and the PS-side mailbox driver of
+    INTEGRATION.md §1) compile as strict C11 with every warning an error (syntax only: no GPU, no library needed)"""
+    r = subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "mini_nbody_amd", "host", prog)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="no gcc")
 def test_cpu_code_is_sanitizer_clean(tmp_path):
     exe = tmp_path / "nbody_cpu_san"
