@@ -1285,9 +1285,12 @@ void serve_loop() {
 }
 
 void serve_stop() {
-  if (g_serve_on.exchange(0, std::memory_order_acq_rel) && g_serve_thread.joinable()) g_serve_thread.join();
-  else if (g_serve_thread.joinable()) g_serve_thread.join();
+  g_serve_on.store(0, std::memory_order_release);
+  if (g_serve_thread.joinable()) g_serve_thread.join();
 }
+// a process that exits while the thread serves (no nbody_shutdown): stop and join it before g_serve_thread is destroyed — a joinable
+// std::thread reaching its destructor ends the process with std::terminate (declared after the thread, hence destroyed before it)
+struct ServeGuard { ~ServeGuard() { serve_stop(); } } g_serve_guard;
 
 }  // namespace
 

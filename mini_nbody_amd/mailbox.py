@@ -60,7 +60,7 @@ class Mailbox:
         self._open = True
         a, b, cap = C.c_void_p(), C.c_void_p(), C.c_int()
         L.check(self.lib.nbody_mailbox_rams(C.byref(a), C.byref(b), C.byref(cap)))
-        self.capacity, self.faithful = cap.value, bool(faithful)
+        self.capacity, self.faithful, self._posted = cap.value, bool(faithful), 0
         self.ram_a = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint32)), shape=(self.capacity + 1, 4))
         self.ram_b = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_float)), shape=(self.capacity, 4))
 
@@ -71,7 +71,9 @@ class Mailbox:
         if n > self.capacity:
             raise ValueError("%d bodies exceed the mailbox's capacity %d" % (n, self.capacity))
         self.ram_a[1:n + 1] = pos.view(np.uint32)
-        self.ram_a[0] = (1, n, 0, 0)
+        self._posted = n
+        self.ram_a[0, 1:] = (n, 0, 0)
+        self.ram_a[0, 0] = 1                  # BEGIN is written last (a served mailbox may take the request at once)
         return n
 
     def run(self, clock_khz=0):
@@ -96,7 +98,7 @@ class Mailbox:
         """What the PS does after raising BEGIN: poll word 0 of RAM A until BEGIN reads 0.  Returns (RAM B words 0..N-1 (view), ticks);
         raises if the library flagged the request (bits 127:96 of word 0, which the RTL always writes as 0)."""
         import time
-        n = int(self.ram_a[0, 1] & 0x7FFF)
+        n = self._posted                       # (word 0 may already hold the tick count: NUM_PTS is what post() wrote)
         w0 = self.ram_a[0]
         t0 = time.perf_counter()
         while w0[0] & 1:

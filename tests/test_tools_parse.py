@@ -22,7 +22,7 @@ def test_shell_tool_parses(path):
     assert r.returncode == 0, r.stderr
 
 
-@pytest.mark.parametrize("tool", ["sweep.py", "mailbox_rate.py"])
+@pytest.mark.parametrize("tool", ["sweep.py", "mailbox_rate.py", "mailbox_soak.py"])
 def test_tool_prints_its_usage(tool):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "-h"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "usage" in r.stdout.lower()
