@@ -88,3 +88,10 @@ def test_mailbox_images(nb):
     assert np.array_equal(ram[1:].view(np.float32), pos)
     with pytest.raises(ValueError):
         nb.mailbox.encode_request(np.zeros((40000, 4), np.float32))   # NUM_PTS is 15 bits, S/top_level.vhd:45
+
+
+def test_old_package_name_is_an_alias(nb):
+    """round 5: the package directory is `mini_nbody_amd/` (importable as written); the hyphenated name of rounds 1-4 still resolves,
+    to the same module object"""
+    import importlib
+    assert importlib.import_module("mini-nbody_amd") is nb and nb.__name__ == "mini_nbody_amd"
