@@ -140,6 +140,18 @@ def cpu_baseline(n, seed, fp64, target_s=15.0):
                       % (what, rows, n, n, t, "-march=native" if path else "-march=x86-64-v3")}
 
 
+def cpu_baseline_program(argv, timeout_s):
+    """The cpu_baseline leg of BASELINE configs[0]: the oracle run as a program (`oracle/nbody_cpu N iters ...`: test infrastructure, timed
+    on this box's host cores as a REPORTED baseline, never a product path) -> (G pairs/s, ms per step, its checksum line, threads)."""
+    import re
+    o = subprocess.run([os.path.join(ROOT, "oracle", "nbody_cpu")] + list(argv), capture_output=True, text=True, timeout=timeout_s)
+    if o.returncode:
+        raise RuntimeError("oracle/nbody_cpu exited with %d: %s" % (o.returncode, o.stderr[-300:]))
+    rate = re.search(r"(\d+) threads\): average ([0-9.]+) Billion Interactions / second \(([0-9.]+) ms / step\)", o.stdout)
+    chk = [l for l in o.stdout.splitlines() if l.startswith("checksum")]
+    return float(rate.group(2)), float(rate.group(3)), (chk[0] if chk else None), int(rate.group(1))
+
+
 def cpu_leg_seconds(world, mode, disabled=False):
     """How long the host-CPU leg may take on a line of `world` GPUs (None: no leg, no `cpu_baseline` key): about 15 s of host work on a
     one-GPU line; on an N > 1 line a 3-second row sample — every line carries a MEASURED baseline, and the other ranks sit at a barrier
@@ -950,7 +962,8 @@ def configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, budget_s):
       config2              N = 65536 fp32, 100 steps, the engine's default kernel                     BASELINE configs[1]
       config2_lds_tile256  the same through the north_star's form: sources tiled into LDS, tile 256   BASELINE configs[1] verbatim
       fp64                 N = 262144 fp64, 3 steps: the arithmetic of BASELINE configs[4] (whose N = 4,194,304 over 8 GPUs is 524,288 per GPU)
-      config1              N = 4096, 10 iterations: the CPU program (oracle/nbody_cpu) beside the GPU host program in strict arithmetic
+      config1              N = 4096, 10 iterations: the CPU program (oracle/nbody_cpu, through cpu_baseline_program(): this configuration's
+                           cpu_baseline leg) beside the GPU host program in strict arithmetic
                            (build/nbody --strict, one sequential sum per body): same checksum line          BASELINE configs[0]
     Each entry {value, ms_per_step, frac (of the 20-flop vector roofline), ...}; the whole pass stops starting new entries once
     budget_s seconds are spent.  A failure is recorded in the entry, not raised."""
@@ -1017,14 +1030,16 @@ def configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, budget_s):
         g_rate, g_ms, g_chk, g_out = run([gpu, "4096", "10", "--strict"])
         m = re.search(r"(\d+) segments x (\d+) pieces, sum block (\d+)", g_out)
         order = ["--sum", "blocked", "--segments", m.group(1), "--wsplit", m.group(2), "--block", m.group(3)]
-        c_rate, c_ms, c_chk, _ = run([cpu, "4096", "10"] + order)
+        c_rate, c_ms, c_chk, c_threads = cpu_baseline_program(["4096", "10"] + order, max(5.0, left() + 5.0))
         # (b) one sequential sum per body — what a plain CPU nbody.c does — on both sides
-        s_c_rate, s_c_ms, s_c_chk, _ = run([cpu, "4096", "10"])
+        s_c_rate, s_c_ms, s_c_chk, _ = cpu_baseline_program(["4096", "10"], max(5.0, left() + 5.0))
         s_g_rate, s_g_ms, s_g_chk, _ = run([gpu, "4096", "10", "--strict", "--sum", "seq", "--jsub", "1", "--wsplit", "1"])
         return {"workload": "N=4096 fp32, 10 iterations (the first is warm-up), strict arithmetic, the engine's own summation order (%s segments x %s pieces, blocks of %s)" % m.groups(),
                 "value": g_rate, "unit": "billion pair-interactions/s", "ms_per_step": g_ms,
                 "gpu_program": "build/nbody 4096 10 --strict", "cpu_program": "oracle/nbody_cpu 4096 10 " + " ".join(order),
                 "cpu_value": c_rate, "cpu_ms_per_step": c_ms, "checksum_gpu": g_chk, "checksum_cpu": c_chk,
+                "cpu_baseline": {"value": c_rate, "unit": "billion pair-interactions/s", "cores": c_threads, "kind": "port",
+                                 "sample": "oracle/nbody_cpu 4096 10 %s: the whole configuration, 9 timed iterations" % " ".join(order)},
                 "sequential_sum": {"gpu_program": "build/nbody 4096 10 --strict --sum seq --jsub 1 --wsplit 1", "cpu_program": "oracle/nbody_cpu 4096 10",
                                    "value": s_g_rate, "ms_per_step": s_g_ms, "cpu_value": s_c_rate, "cpu_ms_per_step": s_c_ms,
                                    "checksum_gpu": s_g_chk, "checksum_cpu": s_c_chk, "checksums_equal": bool(s_g_chk and s_g_chk == s_c_chk)},
