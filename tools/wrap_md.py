@@ -29,8 +29,15 @@ def flow(text, first_indent, rest_indent, width):
             cur, fresh = rest_indent, True
         if fresh:
             if lines and BLOCK_START.match(w + " "):
-                # this word would open a block at the start of a line: keep it on the previous line (over the limit by one word at worst)
-                lines[-1] += " " + w
+                # this word would open a block at the start of a line: the previous line's last word comes down in front of it
+                head, _, last = lines[-1].rstrip().rpartition(" ")
+                if head.strip() and not BLOCK_START.match(last + " "):
+                    lines[-1] = head
+                    cur += last + " " + w
+                else:
+                    lines[-1] += " " + w        # (nothing to bring down: stay on the previous line, a word over the limit at worst)
+                    continue
+                fresh = False
                 continue
             cur += w
             fresh = False
