@@ -11,16 +11,33 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-s
 
 all: lib host oracle microbench
 
-lib: $(PKG)/libnbody_hip.so
-$(PKG)/libnbody_hip.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/force_loop_gfx950.inc include/nbody.h
-	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(CSRC)/nbody_hip.hip -ldl
+# The library = ONE device translation unit (kernels.hip: the nbk kernels + the launch functions that pick an instantiation; ~45 s of hipcc)
+# and three host-only C++ files (context, comm, mailbox: seconds each) behind csrc/nbody_internal.hpp.  A host-side edit relinks in seconds.
+HOSTFLAGS := -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function
+OBJ      := build/obj
+KERNEL_SRC := $(CSRC)/kernels.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/nbody_args.hpp $(CSRC)/force_loop_gfx950.inc
+HOST_HDR := $(CSRC)/nbody_internal.hpp $(CSRC)/nbody_args.hpp include/nbody.h
+HOST_OBJ := $(OBJ)/context.o $(OBJ)/comm.o $(OBJ)/mailbox.o
 
-# The diagnostic library: the same source with -DNBODY_DIAG_LOOPS — the experiment encodings of the hand-scheduled loop and its
-# TIMING-ONLY forms (wrong results) that profiles/r02_loop_diagnostics.md was measured with.  Not part of `all`, never loaded by
-# the package unless NBODY_LIB points at it (tools/profile_diag.sh does).
+lib: $(PKG)/libnbody_hip.so
+$(OBJ)/kernels.o: $(KERNEL_SRC) $(HOST_HDR)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/kernels.hip -o $@
+$(OBJ)/%.o: $(CSRC)/%.cpp $(HOST_HDR)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HOSTFLAGS) -c $< -o $@
+$(PKG)/libnbody_hip.so: $(OBJ)/kernels.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread -o $@ $^ -ldl
+
+# The diagnostic library: the same sources with kernels.hip built -DNBODY_DIAG_LOOPS — the experiment encodings of the hand-scheduled loop
+# and its TIMING-ONLY forms (wrong results) that profiles/r02_loop_diagnostics.md was measured with.  Not part of `all`, never loaded by
+# the package unless NBODY_LIB points at it (tools/profile_diag.sh does).  The host objects are the product's own.
 diag: $(PKG)/libnbody_hip_diag.so
-$(PKG)/libnbody_hip_diag.so: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp $(CSRC)/force_loop_gfx950.inc include/nbody.h
-	$(HIPCC) $(HIPFLAGS) -DNBODY_DIAG_LOOPS -shared -pthread -o $@ $(CSRC)/nbody_hip.hip -ldl
+$(OBJ)/kernels_diag.o: $(KERNEL_SRC) $(HOST_HDR)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DNBODY_DIAG_LOOPS -c $(CSRC)/kernels.hip -o $@
+$(PKG)/libnbody_hip_diag.so: $(OBJ)/kernels_diag.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread -o $@ $^ -ldl
 
 # C host program (north_star: "host code stays in C"): links only the C-ABI
 host: build/nbody build/mailbox_driver
@@ -67,9 +84,9 @@ gen:
 	python3 tools/gen_force_loop.py
 	python3 tools/gen_streams.py
 
-isa: $(CSRC)/nbody_hip.hip $(CSRC)/nbody_kernels.hpp
+isa: $(KERNEL_SRC)
 	@mkdir -p build/isa
-	cd build/isa && $(HIPCC) $(HIPFLAGS) -c ../../$(CSRC)/nbody_hip.hip -save-temps -Rpass-analysis=kernel-resource-usage -o nbody_hip.o 2> resource_usage.txt
+	cd build/isa && $(HIPCC) $(HIPFLAGS) -c ../../$(CSRC)/kernels.hip -save-temps -Rpass-analysis=kernel-resource-usage -o kernels.o 2> resource_usage.txt
 
 clean:
 	rm -rf build $(PKG)/libnbody_hip.so $(PKG)/libnbody_hip_diag.so

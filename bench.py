@@ -163,11 +163,11 @@ def cpu_leg_seconds(world, mode, disabled=False):
 
 def kernel_source_sha():
     """identifies the PRODUCT kernel code a profile was taken on (a profile of an older loop must not be attached to a new one): the
-    three kernel files with everything under `#ifdef NBODY_DIAG_LOOPS` left out — the experiment encodings of `make diag`
+    four kernel files (the device translation unit kernels.hip, the kernels, the launch argument block and the hand-scheduled loop; the host-side context.cpp / comm.cpp / mailbox.cpp are not kernel code) with everything under `#ifdef NBODY_DIAG_LOOPS` left out — the experiment encodings of `make diag`
     (libnbody_hip_diag.so) are not in the product library, and adding one must not orphan the product's profiles"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("nbody_kernels.hpp", "force_loop_gfx950.inc", "nbody_hip.hip"):
+    for f in ("nbody_kernels.hpp", "nbody_args.hpp", "force_loop_gfx950.inc", "kernels.hip"):
         skip = 0
         for line in open(os.path.join(ROOT, "mini_nbody_amd", "csrc", f), "rb").read().splitlines(True):
             t = line.strip()

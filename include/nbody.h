@@ -2,7 +2,7 @@
  *
  * Plain C99: pointers, ints, floats.  No HIP, torch or C++ types cross this
  * boundary.  The library behind it is hand-written HIP for gfx950
- * (mini_nbody_amd/csrc/nbody_hip.hip); there is no CPU fallback: every entry
+ * (mini_nbody_amd/csrc/: kernels.hip + context.cpp, comm.cpp, mailbox.cpp); there is no CPU fallback: every entry
  * point fails with NBODY_ERR_NO_DEVICE when no GPU is usable.
  *
  * WHAT EACH ENTRY POINT REPLACES.  The reference (/root/reference, a VHDL FPGA

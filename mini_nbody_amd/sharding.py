@@ -1,5 +1,5 @@
 """Host-side decomposition of the path — Python mirror of the logic in
-csrc/nbody_kernels.hpp (slice_first, segment_bounds) and csrc/nbody_hip.hip
+csrc/nbody_args.hpp (slice_first, segment_bounds) and csrc/context.cpp
 (ring order, ascending combine), so that it can be exercised on CPU
 (tests/test_sharding_gloo.py) without a GPU.
 

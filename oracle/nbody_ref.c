@@ -216,7 +216,7 @@ void ref_forces_f32(const float *rows, int n_rows, const float *src, int n_src, 
 
 /* ------------------------------------------------------------------------- */
 /* The engine's summation order (ref_order_t in nbody_ref.h).
- * Slices and pieces as mini_nbody_amd/csrc/nbody_kernels.hpp slice_first()/segment_bounds(): slice q of P is balanced
+ * Slices and pieces as mini_nbody_amd/csrc/nbody_args.hpp slice_first()/segment_bounds(): slice q of P is balanced
  * (the first n % P slices have one body more); a slice is cut into `sub` pieces of ceil(len / sub) sources. */
 static int slice_first_(int q, int n, int P) {
   int base = n / P, rem = n % P;
@@ -244,7 +244,7 @@ void ref_piece_bounds(int jb, int je, int w, int ws, int *pb, int *pe) {
 }
 
 /* Per row: for every segment in ascending order { for every piece w of the segment's `wsplit` (1 or 4: the four waves of a
- * workgroup, mini_nbody_amd/csrc/nbody_kernels.hpp piece_bounds()) in ascending order { level 1: a = 0, a = fma(d, inv3, a)
+ * workgroup, mini_nbody_amd/csrc/nbody_args.hpp piece_bounds()) in ascending order { level 1: a = 0, a = fma(d, inv3, a)
  * over a block of sources counted from the piece's first (S/fxyz.vhd:120-127); level 2: b = b + a per finished block };
  * level 3: the segment's sum = ((b_0 + b_1) + b_2) + b_3 — the reference's own remedy, partial sums joined by an adder
  * (S/fxyz.vhd:129-145, S/final_adder.vhd:88-104), in the shape a SIMT workgroup has }, then F = p_0, F = F + p_s.

@@ -22,7 +22,8 @@ def pytest_sessionstart(session):
             os.path.join(ROOT, "oracle", "nbody_cpu"), os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip_diag.so")]
     # ... and again whenever a source is newer than what was built from it: a stale library must not be what the tests (or a gpurun
     # snapshot, which ships the built files) exercise
-    src = [os.path.join(ROOT, "mini_nbody_amd", "csrc", f) for f in ("nbody_hip.hip", "nbody_kernels.hpp", "force_loop_gfx950.inc")] + \
+    src = [os.path.join(ROOT, "mini_nbody_amd", "csrc", f) for f in ("kernels.hip", "context.cpp", "comm.cpp", "mailbox.cpp", "nbody_internal.hpp", "nbody_args.hpp", "nbody_kernels.hpp",
+                                                                      "force_loop_gfx950.inc")] + \
           [os.path.join(ROOT, "include", "nbody.h"), os.path.join(ROOT, "oracle", "nbody_ref.c"), os.path.join(ROOT, "oracle", "nbody_ref.h"),
            os.path.join(ROOT, "oracle", "nbody_cpu.c"), os.path.join(ROOT, "mini_nbody_amd", "host", "nbody.c"),
            os.path.join(ROOT, "mini_nbody_amd", "host", "mailbox_driver.c")]

@@ -26,7 +26,7 @@ STUB = textwrap.dedent('''
     if transport not in ("host", "peer") or (transport == "peer" and mode.endswith("twice")):
         mode = mode.replace("twice", "")
         if mode == "fail" and rank == world - 1:
-            sys.stderr.write("RCCL error 5 near nbody_hip.hip:123\\n")
+            sys.stderr.write("RCCL error 5 near comm.cpp:123\\n")
             sys.exit(3)
         if mode in ("hang", "fail"):
             time.sleep(3600)      # a hang; or the others wait in a collective for the rank that died

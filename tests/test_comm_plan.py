@@ -1,5 +1,5 @@
 """The transfer plan the library executes for P > 1 ranks (nbody_comm_plan in include/nbody.h: the pure host function
-rccl_gather() in csrc/nbody_hip.hip walks), checked without a GPU for P = 2..8 and ragged N:
+rccl_gather() in csrc/comm.cpp walks), checked without a GPU for P = 2..8 and ragged N:
   * against the Python mirror of the schedule (mini_nbody_amd/sharding.py ring_schedule / direct_schedule),
   * every word of every other rank's slice is received exactly once, nothing lands in the rank's own slice,
   * pair s of rank r matches a pair of its peer in the same RCCL group: same word range, peer addressed back,

@@ -96,8 +96,9 @@ def test_kernel_source_sha_ignores_the_diagnostic_build(tmp_path, monkeypatch):
     d = tmp_path / "mini_nbody_amd" / "csrc"
     d.mkdir(parents=True)
     base = {"nbody_kernels.hpp": "int a;\n#ifdef NBODY_DIAG_LOOPS\nint diag1;\n#if X\nint nested;\n#endif\n#endif\nint b;\n",
+            "nbody_args.hpp": "struct ForceArgs { int n; };\n",
             "force_loop_gfx950.inc": "#define P 1\n#ifdef NBODY_DIAG_LOOPS\n#define V19 2\n#endif  // NBODY_DIAG_LOOPS\n",
-            "nbody_hip.hip": "#ifdef NBODY_DIAG_LOOPS\nreturn 1;\n#else\nreturn 0;\n#endif\n#ifndef NBODY_DIAG_LOOPS\nint product_only;\n#endif\n"}
+            "kernels.hip": "#ifdef NBODY_DIAG_LOOPS\nreturn 1;\n#else\nreturn 0;\n#endif\n#ifndef NBODY_DIAG_LOOPS\nint product_only;\n#endif\n"}
 
     def sha(files):
         for k, v in files.items():
@@ -108,9 +109,9 @@ def test_kernel_source_sha_ignores_the_diagnostic_build(tmp_path, monkeypatch):
     h0 = sha(base)
     assert sha(dict(base, **{"nbody_kernels.hpp": base["nbody_kernels.hpp"].replace("int diag1;", "int diag1; int diag2;").replace("int nested;", "")})) == h0
     assert sha(dict(base, **{"force_loop_gfx950.inc": base["force_loop_gfx950.inc"].replace("#define V19 2", "#define V19 2\n#define V20 3")})) == h0
-    assert sha(dict(base, **{"nbody_hip.hip": base["nbody_hip.hip"].replace("return 1;", "return 2;")})) == h0
-    assert sha(dict(base, **{"nbody_hip.hip": base["nbody_hip.hip"].replace("return 0;", "return 3;")})) != h0          # the product's side of the #else
-    assert sha(dict(base, **{"nbody_hip.hip": base["nbody_hip.hip"].replace("int product_only;", "int product_only2;")})) != h0   # #ifndef: product code
+    assert sha(dict(base, **{"kernels.hip": base["kernels.hip"].replace("return 1;", "return 2;")})) == h0
+    assert sha(dict(base, **{"kernels.hip": base["kernels.hip"].replace("return 0;", "return 3;")})) != h0          # the product's side of the #else
+    assert sha(dict(base, **{"kernels.hip": base["kernels.hip"].replace("int product_only;", "int product_only2;")})) != h0   # #ifndef: product code
     assert sha(dict(base, **{"nbody_kernels.hpp": base["nbody_kernels.hpp"].replace("int b;", "int c;")})) != h0
 
 

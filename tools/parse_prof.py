@@ -76,7 +76,7 @@ def main():
             import hashlib
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             h = hashlib.sha1()
-            for f in ("nbody_kernels.hpp", "force_loop_gfx950.inc", "nbody_hip.hip"):
+            for f in ("nbody_kernels.hpp", "nbody_args.hpp", "force_loop_gfx950.inc", "kernels.hip"):
                 h.update(open(os.path.join(root, "mini_nbody_amd", "csrc", f), "rb").read())
             if h.hexdigest()[:12] == cfg["kernel_source_sha"]:
                 sys.path.insert(0, root)
