@@ -10,7 +10,8 @@
  * boundary is a memory-mapped mailbox:
  *   - bodies in:  128-bit words {x, y, z, ignored} at word k = 1..N of RAM A    S/top_level.vhd:206-208, 238-240, 280
  *   - start:      word 0 = {bit 0 BEGIN, bits 46:32 NUM_PTS}                   S/top_level.vhd:184-185
- *   - forces out: 128-bit words {Fx, Fy, Fz, 0} at word k-1 of RAM B           S/compute_store.vhd:213, 227-242
+ *   - forces out: 128-bit words {Fx, Fy, Fz, 0}: body k's at word k of RAM B,  S/compute_store.vhd:213, 221-242
+ *                 word 0 never written
  *   - done:       word 0 rewritten with {ticks in bits 63:32}, BEGIN reads 0   S/top_level.vhd:146, 255-263
  *   - one request in flight; BEGIN ignored while busy                          S/top_level.vhd:180-186
  * The names bodyForce()/integrate() and the {pos, vel} layout come from
@@ -20,7 +21,8 @@
  * Conventions: every function returns 0 (NBODY_OK) on success; a positive value
  * < 1000 is a hipError_t, 1000..1999 an NBODY_ERR_*, 2000 + r an ncclResult_t r.
  * The caller owns host buffers, the library owns device buffers.  One context
- * per process, not thread-safe (the reference's single in-flight request).
+ * per process, not thread-safe (the reference's single in-flight request); the one second thread the library knows — the mailbox's
+ * service thread — locks every other caller out while it serves (nbody_mailbox_serve).
  */
 #ifndef NBODY_H
 #define NBODY_H
@@ -231,9 +233,16 @@ int nbody_forces_d(const double *pos_words, double *force_words, int n);
 int nbody_forces_rows(int first_row, int n_rows, float *force_words);
 int nbody_forces_rows_d(int first_row, int n_rows, double *force_words);
 
-/* ---- the reference's mailbox, verbatim (its ONLY interface) ----
+/* ---- the reference's mailbox (its ONLY interface): the protocol the RTL intends ----
  * RAM A = capacity + 1 words of 16 bytes: word 0 = control {bit 0 BEGIN, bits 46:32 NUM_PTS}, words 1..N = {x, y, z, ignored}
- * (S/top_level.vhd:184-185, 206-208); RAM B = capacity words: word k-1 = {Fx, Fy, Fz, 0} of body k (S/compute_store.vhd:213, 242).
+ * (S/top_level.vhd:184-185, 206-208).  RAM B = capacity + 1 words: word k = {Fx, Fy, Fz, 0} of body k — the index the body has in RAM A —
+ * and word 0 is NEVER written (S/compute_store.vhd:213, 221-242: write_we and STORE_PTR + 1 are registered on the same edge and write_addr
+ * is formed from STORE_PTR combinationally, so the RAM samples we = 1 with the incremented address; the cycle model of those lines is
+ * tests/test_fpga_store_model.py.  The signal's name, ZERO_PTR, :76-77, suggests the author meant word k - 1; the RTL does not do it.)
+ * "The protocol the RTL intends", not "the RTL verbatim": the sequencer as written breaks that protocol in six places (NUM_PTS <= 3 is
+ * never streamed, uninitialised pointers, `waiting` polls word 1, a stale BEGIN starts a second pass, NUM_PTS >= 32761 never ends,
+ * `complete` overtakes the last block-group's stores) — shown cycle by cycle in tests/test_fpga_fsm_model.py, listed with what this
+ * library does instead in INTEGRATION.md ("Departures from the RTL as written").  None of them is reproduced.
  *
  * nbody_mailbox_open(capacity, faithful): power-up of the PL block — ONE context that then serves any number of requests of any size.
  *   capacity = body words of the two RAMs, 1..32767 (= ram_depth - 1, S/top_level.vhd:45); 0 means 32767.  Replaces any open context.
@@ -242,28 +251,37 @@ int nbody_forces_rows_d(int first_row, int n_rows, double *force_words);
  *   S/final_adder.vhd:88-104) + NBODY_OPT_JSUB 1 (one stream of all N sources per body, S/top_level.vhd:233-254) — granted only after the
  *   device has proved the strict 1/sqrt (nbody_strict_proof; NBODY_ERR_UNSUPPORTED and no context otherwise).  faithful = 0: the
  *   engine's timed arithmetic (every force within 1e-5 of the RTL's, not bit-equal).  nbody_shutdown() closes it.
- * nbody_mailbox_rams(): the context's own RAM images — pinned host memory the device reads (RAM A) and writes (RAM B) directly, the PS's
- *   view of the two block RAMs (S/top_level.vhd:100-117, 148-163).  A driver that fills *ram_a and passes these two pointers to
- *   nbody_mailbox_run moves no byte on the host; any other host buffers are accepted too and cost one host copy each way.
- *   *capacity (may be NULL) = the largest NUM_PTS the context takes.  Works in any one-GPU fp32 context (nbody_init(n, 1, 0, .): capacity n).
+ * nbody_mailbox_rams(): the context's own RAM images — pinned host memory the device reads (RAM A) and writes (RAM B, and word 0 of RAM A
+ *   on completion) directly, the PS's view of the two block RAMs (S/top_level.vhd:100-117, 148-163).  A driver that fills *ram_a and passes
+ *   these two pointers to nbody_mailbox_run moves no byte on the host; any other host buffers (of NUM_PTS + 1 words each) are accepted too
+ *   and cost one host copy each way.  *capacity (may be NULL) = the largest NUM_PTS the context takes.  Works in any one-GPU fp32 context
+ *   (nbody_init(n, 1, 0, .): capacity n).
  * nbody_mailbox_run(ram_a, ram_b, clock_khz): ONE request, synchronous (one request in flight, S/top_level.vhd:180-186).
  *   NUM_PTS is sampled from word 0 with every request (S/top_level.vhd:180-186): any value 0..capacity, request after request, on the
- *   same context.  Words >= NUM_PTS of RAM B are never written (S/compute_store.vhd:227-232); NUM_PTS = 0 completes at once with RAM B
- *   untouched (S/top_level.vhd:189-192).  On return word 0 of ram_a is {ticks in bits 63:32, 0 elsewhere} — BEGIN reads 0 — with
- *   ticks = 1 + elapsed time BEGIN-to-done in units of 1000 clocks of `clock_khz` (0: 300 MHz), as S/top_level.vhd:121-146, 255-263
- *   count them.  Returns NBODY_ERR_STATE if BEGIN is not set (the FSM stays in `waiting`: nothing read, nothing written),
- *   NBODY_ERR_ARG if NUM_PTS exceeds the capacity (the RTL has no such case: its RAM always holds 32767 bodies).
+ *   same context — 1, 2 and 3 included (the RTL as written stores nothing for those: a stated departure).  Word 0 of RAM B and the words
+ *   beyond NUM_PTS are never written (S/compute_store.vhd:221-242); NUM_PTS = 0 completes at once with RAM B untouched
+ *   (S/top_level.vhd:189-192).  On return word 0 of ram_a is {ticks in bits 63:32, 0 elsewhere} — BEGIN reads 0.
+ *   COMPLETION IS THE DEVICE'S, as in the PL block (S/top_level.vhd:121-146, 255-263): the last launch of a request rewrites word 0 of the
+ *   pinned RAM A itself — ticks = 1 + the elapsed 1000-clock units of a `clock_khz` clock (0: 300 MHz) between the first wave that reads
+ *   RAM A and that store, counted on the device's real-time counter — and clears BEGIN last, after every word of RAM B; the host only
+ *   polls memory.  (NUM_PTS = 0, a refused request, a context over several ranks: the host writes word 0, ticks from its own clock.)
+ *   Returns NBODY_ERR_STATE if BEGIN is not set (the FSM stays in `waiting`: nothing read, nothing written), NBODY_ERR_ARG if NUM_PTS
+ *   exceeds the capacity (the RTL has no such case: its RAM always holds 32767 bodies).
  *   The context's N, options, uploaded state's size and step graph are as before on return (its position buffer is overwritten, as by
  *   nbody_forces).  A context over several devices or ranks keeps its fixed N (NUM_PTS must equal it).
  * nbody_mailbox_serve(on, clock_khz): the mailbox WITHOUT a call per request.  on = 1: a library thread takes the place of the PL block's
- *   FSM — it samples word 0 of the context's own RAM A (nbody_mailbox_rams) as the RTL does every clock (S/top_level.vhd:180-186), runs
- *   each request it finds exactly as nbody_mailbox_run would, and rewrites word 0 (ticks in bits 63:32, BEGIN cleared LAST, so whoever
- *   reads BEGIN = 0 also reads the ticks and RAM B).  The driver then only writes memory — bodies, then word 0 with NUM_PTS and BEGIN —
- *   and polls word 0, as the PS does.  A request the library cannot take (NUM_PTS beyond the capacity, a device error) completes with
- *   ticks = 0 and the error code in bits 127:96 of word 0, which the RTL always writes as 0.  While serving, the calling thread must
- *   leave the context alone (nbody_mailbox_run answers NBODY_ERR_STATE; nbody_get_info is safe; NBODY_INFO_MAILBOX_SERVED counts
- *   completed requests); on = 0 (and nbody_shutdown) stops and joins the thread.  The idle thread backs off from spinning to 50-us naps
- *   after ~0.1 s without a request.  One-GPU fp32 contexts only. */
+ *   FSM — it samples word 0 of the context's own RAM A (nbody_mailbox_rams) as the RTL does every clock (S/top_level.vhd:180-186) and runs
+ *   each request it finds exactly as nbody_mailbox_run would; the device rewrites word 0 (ticks in bits 63:32, BEGIN cleared LAST, so
+ *   whoever reads BEGIN = 0 also reads the ticks and RAM B).  The driver then only writes memory — bodies, then word 0 with NUM_PTS and
+ *   BEGIN — and polls word 0, as the PS does.  A request the library cannot take (NUM_PTS beyond the capacity, a device error) completes
+ *   with ticks = 0 and the error code in bits 127:96 of word 0, which the RTL always writes as 0.
+ *   WHILE SERVING THE THREAD OWNS THE CONTEXT: every entry point that launches, copies or reconfigures (nbody_init*, nbody_mailbox_open,
+ *   nbody_mailbox_run, nbody_set_option, nbody_upload*, nbody_download*, nbody_step*, nbody_sync, bodyForce*, integrate*, nbody_forces*,
+ *   nbody_kernel_time, nbody_comm_*, nbody_device_ptr, the 1/sqrt self-tests) answers NBODY_ERR_STATE from any other thread;
+ *   nbody_get_info reports the context's own N and configuration (never a request's), NBODY_INFO_MAILBOX_SERVED counts completed
+ *   requests; nbody_mailbox_rams, nbody_error_string, nbody_mailbox_serve and nbody_shutdown stay available.  on = 0 (and
+ *   nbody_shutdown) stops and joins the thread.  The idle thread backs off from spinning to 50-us naps after ~0.1 s without a request.
+ *   One-GPU fp32 contexts only. */
 int nbody_mailbox_open(int capacity, int faithful);
 int nbody_mailbox_rams(void **ram_a, void **ram_b, int *capacity);
 int nbody_mailbox_run(void *ram_a, void *ram_b, int clock_khz);

@@ -271,7 +271,7 @@ int nbody_unique_id(void* uid128) {
 // through rccl_gather() in the configured NBODY_OPT_COMM form, (2) one ring step (ncclSend to rank+1, ncclRecv from
 // rank-1, grouped) of a patterned block — with one rank both are device-local, which is how a one-GPU box exercises
 // the library's RCCL calls (symbols, argument order, byte counts).  Every received word is checked on the host.
-int nbody_comm_selftest(long long* bytes_moved) {
+int nbody_comm_selftest(long long* bytes_moved) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (!g.multiprocess) return NBODY_ERR_STATE;
   Local& L = g.loc[0];
@@ -322,7 +322,7 @@ int nbody_comm_selftest(long long* bytes_moved) {
 // the k-th send with the k-th receive of a group, so issuing them pairwise reproduces exactly the P-rank exchange.
 // Afterwards every array must hold all N words.  This runs the plan's offsets, byte counts and send/recv pairing of both
 // forms on hardware, which a one-rank job's own plan (P - 1 = 0 pairs) never does.
-int nbody_comm_selftest_virtual(int vp, int form, long long* bytes_moved) {
+int nbody_comm_selftest_virtual(int vp, int form, long long* bytes_moved) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (!g.multiprocess || g.nranks != 1) return NBODY_ERR_STATE;
   Local& L = g.loc[0];
@@ -406,7 +406,7 @@ int nbody_comm_plan(int form, int rank, int nranks, int n, long long* ops, int m
 //   4  the same with the hand-shake enqueue_step() uses: pass B waits for an event the transfer stream records right
 //      before its RCCL kernel (L.ev_comm_go), so the RCCL kernel's packet is at the head of its queue when B is released.
 // *force_ms: the duration of the (last) force pass.
-int nbody_comm_probe(long long bytes, int when, double* comm_ms, double* force_ms) {
+int nbody_comm_probe(long long bytes, int when, double* comm_ms, double* force_ms) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (!g.multiprocess) return NBODY_ERR_STATE;
   Local& L = g.loc[0];
@@ -458,7 +458,7 @@ int nbody_comm_probe(long long bytes, int when, double* comm_ms, double* force_m
   return NBODY_OK;
 }
 
-int nbody_set_host_gather(nbody_host_gather_fn fn, void* user) {
+int nbody_set_host_gather(nbody_host_gather_fn fn, void* user) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (!g.multiprocess) return NBODY_ERR_STATE;
   g.host_gather = (host_gather_fn)fn;

@@ -17,8 +17,8 @@ using namespace nbk;
 
 namespace nbi {
 
-const char* g_last_file = "";
-int g_last_line = 0;
+std::atomic<const char*> g_last_file{""};
+std::atomic<int> g_last_line{0};
 Global g;
 
 namespace {
@@ -215,6 +215,8 @@ int reconfigure() {
       HIPC(hipMemsetAsync(L.tickets, 0, ticket_words(L.n_local) * sizeof(unsigned), L.compute));
     }
   }
+  g.view.n = g.n; g.view.n_local = g.loc[0].n_local; g.view.variant = g.variant; g.view.R = g.R; g.view.sub = g.sub; g.view.nseg = g.nseg;
+  g.view.fuse = g.fuse; g.view.wsplit = g.wsplit;
   return NBODY_OK;
 }
 
@@ -709,7 +711,7 @@ using namespace nbi;
 // ============================================================================
 extern "C" {
 
-int nbody_init(int n, int ngpus, int fp64, int tile) {
+int nbody_init(int n, int ngpus, int fp64, int tile) { NB_REFUSE_WHILE_SERVED();
   if (g.init) nbody_shutdown();
   if (ngpus <= 0 || ngpus > kMaxLocal) return NBODY_ERR_ARG;
   NBC(init_common(n, fp64, tile));
@@ -753,7 +755,7 @@ int nbody_init(int n, int ngpus, int fp64, int tile) {
   return NBODY_OK;
 }
 
-int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void* uid128) {
+int nbody_init_rank(int n, int fp64, int tile, int rank, int nranks, const void* uid128) { NB_REFUSE_WHILE_SERVED();
   if (g.init) nbody_shutdown();
   if (nranks <= 0 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return NBODY_ERR_ARG;
   NBC(init_common(n, fp64, tile));   // uid128 == NULL with nranks > 1: no RCCL, nbody_set_host_gather() must follow
@@ -817,7 +819,7 @@ static int rsqrt_selftest_on(int dev, unsigned first_bits, unsigned long long co
   return NBODY_OK;
 }
 
-int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned long long* mismatches, unsigned long long* ieee_lanes, unsigned* first_bad) {
+int nbody_rsqrt_selftest(unsigned first_bits, unsigned long long count, unsigned long long* mismatches, unsigned long long* ieee_lanes, unsigned* first_bad) { NB_REFUSE_WHILE_SERVED();
   if (count == 0 || count > (1ull << 32) || (unsigned long long)first_bits + count > (1ull << 32)) return NBODY_ERR_ARG;
   const int dev = rsqrt_device();
   if (dev < 0) return NBODY_ERR_NO_DEVICE;
@@ -852,7 +854,7 @@ static int prove_strict_context() {
   return NBODY_OK;
 }
 
-int nbody_strict_proof(unsigned long long* mismatches, unsigned* first_bad) {
+int nbody_strict_proof(unsigned long long* mismatches, unsigned* first_bad) { NB_REFUSE_WHILE_SERVED();
   int rc;
   if (g.init) rc = prove_strict_context();
   else { const int dev = rsqrt_device(); if (dev < 0) return NBODY_ERR_NO_DEVICE; rc = prove_strict_on(dev); }
@@ -861,7 +863,7 @@ int nbody_strict_proof(unsigned long long* mismatches, unsigned* first_bad) {
   return rc;
 }
 
-int nbody_rsqrt_strict(const float* x, float* y, int n, int ieee_only) {
+int nbody_rsqrt_strict(const float* x, float* y, int n, int ieee_only) { NB_REFUSE_WHILE_SERVED();
   if (!x || !y || n <= 0) return NBODY_ERR_ARG;
   const int dev = rsqrt_device();
   if (dev < 0) return NBODY_ERR_NO_DEVICE;
@@ -884,7 +886,7 @@ void nbody_shutdown(void) {
   g.init = false; g.nlocal = 0; g.nranks = 1;
 }
 
-int nbody_set_option(int key, int value) {
+int nbody_set_option(int key, int value) { NB_REFUSE_WHILE_SERVED();
   switch (key) {
     case NBODY_OPT_VARIANT: if (value < 0 || value > 4) return NBODY_ERR_ARG; g.opt.variant = value; break;
     case NBODY_OPT_IBLOCK: if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NBODY_ERR_ARG; g.opt.iblock = value; break;
@@ -922,15 +924,15 @@ int nbody_get_info(int key, long long* value) {
   if (!g.init) return NBODY_ERR_NOT_INIT;
   const Local& L = g.loc[0];
   switch (key) {
-    case NBODY_INFO_N: *value = g.n; break;
-    case NBODY_INFO_N_LOCAL: *value = L.n_local; break;
+    case NBODY_INFO_N: *value = g.view.n; break;
+    case NBODY_INFO_N_LOCAL: *value = g.view.n_local; break;
     case NBODY_INFO_FIRST_BODY: *value = L.first; break;
     case NBODY_INFO_RANK: *value = L.rank; break;
     case NBODY_INFO_NRANKS: *value = g.nranks; break;
-    case NBODY_INFO_VARIANT: *value = g.variant; break;
-    case NBODY_INFO_IBLOCK: *value = g.R; break;
-    case NBODY_INFO_JSUB: *value = g.sub; break;
-    case NBODY_INFO_NSEG: *value = g.nseg; break;
+    case NBODY_INFO_VARIANT: *value = g.view.variant; break;
+    case NBODY_INFO_IBLOCK: *value = g.view.R; break;
+    case NBODY_INFO_JSUB: *value = g.view.sub; break;
+    case NBODY_INFO_NSEG: *value = g.view.nseg; break;
     case NBODY_INFO_DEVICE: *value = L.device; break;
     case NBODY_INFO_CU_COUNT: *value = g.cu_count; break;
     case NBODY_INFO_CLOCK_KHZ: *value = g.clock_khz; break;
@@ -941,15 +943,15 @@ int nbody_get_info(int key, long long* value) {
     case NBODY_INFO_SUM_BLOCK: *value = (!g.fp64 && g.opt.sum_order == NBODY_SUM_BLOCKED) ? g.opt.sum_block : 0; break;
     case NBODY_INFO_LAUNCHES_PER_STEP: {
       const int force = g.nranks == 1 ? 1 : (g.opt.overlap == 2 ? g.nranks : (g.opt.overlap ? 2 : 1));
-      *value = force + (finish_mode() == kFinishStore ? 1 : 0);
+      *value = force + ((g.view.nseg > 1 && !g.view.fuse) ? 1 : 0);   // (finish_mode() of the context's own configuration)
       break;
     }
     case NBODY_INFO_HAS_COMM: *value = L.comm_h ? 1 : 0; break;
-    case NBODY_INFO_WSPLIT: *value = g.wsplit; break;
+    case NBODY_INFO_WSPLIT: *value = g.view.wsplit; break;
     case NBODY_INFO_ISA_PHASE: *value = g.opt.isa_phase; break;
     case NBODY_INFO_LONG_BUFFERS: *value = g.opt.long_buffers; break;
     case NBODY_INFO_XCD_MAP: *value = g.opt.xcd_map; break;
-    case NBODY_INFO_FUSE_COMBINE: *value = g.fuse; break;
+    case NBODY_INFO_FUSE_COMBINE: *value = g.view.fuse; break;
     case NBODY_INFO_COMM_FORM: *value = g.nranks > 1 ? resolved_comm_form() : -1; break;
     case NBODY_INFO_COMM_PRIORITY: *value = g.comm_priority; break;
     case NBODY_INFO_MAILBOX_SERVED: *value = mailbox_served(); break;
@@ -980,13 +982,13 @@ const char* nbody_error_string(int code) {
       return "nbody: not supported in this configuration";
     default: break;
   }
-  if (code > 0 && code < 1000) { snprintf(buf, sizeof(buf), "HIP error %d (%s) near %s:%d", code, hipGetErrorString((hipError_t)code), base_name(g_last_file), g_last_line); return buf; }
-  if (code >= 2000) { snprintf(buf, sizeof(buf), "RCCL error %d near %s:%d", code - 2000, base_name(g_last_file), g_last_line); return buf; }
+  if (code > 0 && code < 1000) { snprintf(buf, sizeof(buf), "HIP error %d (%s) near %s:%d", code, hipGetErrorString((hipError_t)code), base_name(g_last_file.load(std::memory_order_relaxed)), g_last_line.load(std::memory_order_relaxed)); return buf; }
+  if (code >= 2000) { snprintf(buf, sizeof(buf), "RCCL error %d near %s:%d", code - 2000, base_name(g_last_file.load(std::memory_order_relaxed)), g_last_line.load(std::memory_order_relaxed)); return buf; }
   snprintf(buf, sizeof(buf), "nbody: unknown error %d", code);
   return buf;
 }
 
-int nbody_download_slice(void* pos_words, void* vel_words) {
+int nbody_download_slice(void* pos_words, void* vel_words) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (!pos_words || !vel_words) return NBODY_ERR_ARG;
   if (g.nlocal != 1) return NBODY_ERR_UNSUPPORTED;      // one process driving several devices owns every slice: nbody_download
@@ -999,27 +1001,27 @@ int nbody_download_slice(void* pos_words, void* vel_words) {
   return NBODY_OK;
 }
 
-int nbody_upload(const BodySystem* host) { if (!host) return NBODY_ERR_ARG; if (g.init && g.fp64) return NBODY_ERR_STATE; return upload_impl(host->pos, host->vel); }
-int nbody_download(BodySystem* host) { if (!host) return NBODY_ERR_ARG; if (g.init && g.fp64) return NBODY_ERR_STATE; return download_impl(host->pos, host->vel); }
-int nbody_upload_d(const BodySystemD* host) { if (!host) return NBODY_ERR_ARG; if (g.init && !g.fp64) return NBODY_ERR_STATE; return upload_impl(host->pos, host->vel); }
-int nbody_download_d(BodySystemD* host) { if (!host) return NBODY_ERR_ARG; if (g.init && !g.fp64) return NBODY_ERR_STATE; return download_impl(host->pos, host->vel); }
+int nbody_upload(const BodySystem* host) { NB_REFUSE_WHILE_SERVED(); if (!host) return NBODY_ERR_ARG; if (g.init && g.fp64) return NBODY_ERR_STATE; return upload_impl(host->pos, host->vel); }
+int nbody_download(BodySystem* host) { NB_REFUSE_WHILE_SERVED(); if (!host) return NBODY_ERR_ARG; if (g.init && g.fp64) return NBODY_ERR_STATE; return download_impl(host->pos, host->vel); }
+int nbody_upload_d(const BodySystemD* host) { NB_REFUSE_WHILE_SERVED(); if (!host) return NBODY_ERR_ARG; if (g.init && !g.fp64) return NBODY_ERR_STATE; return upload_impl(host->pos, host->vel); }
+int nbody_download_d(BodySystemD* host) { NB_REFUSE_WHILE_SERVED(); if (!host) return NBODY_ERR_ARG; if (g.init && !g.fp64) return NBODY_ERR_STATE; return download_impl(host->pos, host->vel); }
 
-int bodyForce(float* pos, float* vel, float dt, int n) { if (g.init && g.fp64) return NBODY_ERR_STATE; return body_force_impl(pos, vel, dt, (double)dt, n); }
-int integrate(float* pos, const float* vel, float dt, int n) { if (g.init && g.fp64) return NBODY_ERR_STATE; return integrate_impl(pos, vel, dt, (double)dt, n); }
-int bodyForce_d(double* pos, double* vel, double dt, int n) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return body_force_impl(pos, vel, (float)dt, dt, n); }
-int integrate_d(double* pos, const double* vel, double dt, int n) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return integrate_impl(pos, vel, (float)dt, dt, n); }
+int bodyForce(float* pos, float* vel, float dt, int n) { NB_REFUSE_WHILE_SERVED(); if (g.init && g.fp64) return NBODY_ERR_STATE; return body_force_impl(pos, vel, dt, (double)dt, n); }
+int integrate(float* pos, const float* vel, float dt, int n) { NB_REFUSE_WHILE_SERVED(); if (g.init && g.fp64) return NBODY_ERR_STATE; return integrate_impl(pos, vel, dt, (double)dt, n); }
+int bodyForce_d(double* pos, double* vel, double dt, int n) { NB_REFUSE_WHILE_SERVED(); if (g.init && !g.fp64) return NBODY_ERR_STATE; return body_force_impl(pos, vel, (float)dt, dt, n); }
+int integrate_d(double* pos, const double* vel, double dt, int n) { NB_REFUSE_WHILE_SERVED(); if (g.init && !g.fp64) return NBODY_ERR_STATE; return integrate_impl(pos, vel, (float)dt, dt, n); }
 
-int nbody_step(float dt, int nsteps) { if (g.init && g.fp64) return NBODY_ERR_STATE; return step_impl(dt, (double)dt, nsteps); }
-int nbody_step_d(double dt, int nsteps) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return step_impl((float)dt, dt, nsteps); }
-int nbody_sync(void) { if (!g.init) return NBODY_ERR_NOT_INIT; return sync_all(); }
+int nbody_step(float dt, int nsteps) { NB_REFUSE_WHILE_SERVED(); if (g.init && g.fp64) return NBODY_ERR_STATE; return step_impl(dt, (double)dt, nsteps); }
+int nbody_step_d(double dt, int nsteps) { NB_REFUSE_WHILE_SERVED(); if (g.init && !g.fp64) return NBODY_ERR_STATE; return step_impl((float)dt, dt, nsteps); }
+int nbody_sync(void) { NB_REFUSE_WHILE_SERVED(); if (!g.init) return NBODY_ERR_NOT_INIT; return sync_all(); }
 
-int nbody_forces(const float* pos_words, float* force_words, int n) { if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
-int nbody_forces_d(const double* pos_words, double* force_words, int n) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
+int nbody_forces(const float* pos_words, float* force_words, int n) { NB_REFUSE_WHILE_SERVED(); if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
+int nbody_forces_d(const double* pos_words, double* force_words, int n) { NB_REFUSE_WHILE_SERVED(); if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_impl(pos_words, force_words, n); }
 
-int nbody_forces_rows(int first_row, int n_rows, float* force_words) { if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
-int nbody_forces_rows_d(int first_row, int n_rows, double* force_words) { if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
+int nbody_forces_rows(int first_row, int n_rows, float* force_words) { NB_REFUSE_WHILE_SERVED(); if (g.init && g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
+int nbody_forces_rows_d(int first_row, int n_rows, double* force_words) { NB_REFUSE_WHILE_SERVED(); if (g.init && !g.fp64) return NBODY_ERR_STATE; return forces_rows_impl(first_row, n_rows, force_words); }
 
-int nbody_kernel_time(double* ms_total, long long* launches, int reset) {
+int nbody_kernel_time(double* ms_total, long long* launches, int reset) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   double ms = 0.0; long long n = 0;
   for (int l = 0; l < g.nlocal; ++l) {
@@ -1035,7 +1037,7 @@ int nbody_kernel_time(double* ms_total, long long* launches, int reset) {
   return NBODY_OK;
 }
 
-int nbody_comm_time(double* wait_ms_total, long long* waits, int reset) {
+int nbody_comm_time(double* wait_ms_total, long long* waits, int reset) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   double ms = 0.0; long long n = 0;
   for (int l = 0; l < g.nlocal; ++l) {
@@ -1051,7 +1053,7 @@ int nbody_comm_time(double* wait_ms_total, long long* waits, int reset) {
   return NBODY_OK;
 }
 
-int nbody_device_ptr(int which, void** ptr, size_t* bytes) {
+int nbody_device_ptr(int which, void** ptr, size_t* bytes) { NB_REFUSE_WHILE_SERVED();
   if (!g.init) return NBODY_ERR_NOT_INIT;
   if (!ptr) return NBODY_ERR_ARG;
   Local& L = g.loc[0];

@@ -175,10 +175,18 @@ NBL_HIDDEN int launch_drift_kernel(int fp64, hipStream_t st, void* pos_rows, con
   return (int)hipGetLastError();
 }
 
-// RAM A's read port: body words of the host's RAM image into the resident source array (S/top_level.vhd:206-208, 238-240)
-NBL_HIDDEN int launch_ingest_kernel(hipStream_t st, void* dst_words, const void* ram_a_bodies, int n) {
+// RAM A's read port: body words of the host's RAM image into the resident source array (S/top_level.vhd:206-208, 238-240); t0 (may be
+// null): where its first wave stamps the start of the request's tick count
+NBL_HIDDEN int launch_ingest_kernel(hipStream_t st, void* dst_words, const void* ram_a_bodies, int n, unsigned long long* t0) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(ingest_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (f4*)dst_words, (const f4*)ram_a_bodies, n);
+  hipLaunchKernelGGL(ingest_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (f4*)dst_words, (const f4*)ram_a_bodies, n, t0);
+  return (int)hipGetLastError();
+}
+
+// `complete` written by the device: word 0 of RAM A <- {ticks, BEGIN = 0}, then the library's sequence word (S/top_level.vhd:255-263)
+NBL_HIDDEN int launch_mailbox_done_kernel(hipStream_t st, void* word0, unsigned* seq_word, const unsigned long long* t0, unsigned seq,
+                                          unsigned clock_khz, unsigned rt_khz) {
+  hipLaunchKernelGGL(mailbox_done_kernel, dim3(1), dim3(64), 0, st, (unsigned*)word0, seq_word, t0, seq, clock_khz, rt_khz);
   return (int)hipGetLastError();
 }
 

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #pragma GCC visibility push(default)
@@ -32,10 +33,13 @@ namespace nbi {
 
 using nbk::ForceArgs;
 
-// where the last HIP / RCCL error was seen (nbody_error_string)
-extern const char* g_last_file;
-extern int g_last_line;
-#define NB_MARK() do { ::nbi::g_last_file = __FILE__; ::nbi::g_last_line = __LINE__; } while (0)
+// where the last HIP / RCCL error was seen (nbody_error_string); atomics: the mailbox's service thread may be the one that saw it
+extern std::atomic<const char*> g_last_file;
+extern std::atomic<int> g_last_line;
+#define NB_MARK() do { ::nbi::g_last_file.store(__FILE__, std::memory_order_relaxed); ::nbi::g_last_line.store(__LINE__, std::memory_order_relaxed); } while (0)
+// While nbody_mailbox_serve(1, .) is in effect the service thread owns the context: every entry point that launches, copies or
+// reconfigures answers NBODY_ERR_STATE (nbody_get_info, nbody_error_string, nbody_mailbox_rams, nbody_mailbox_serve and nbody_shutdown do not)
+#define NB_REFUSE_WHILE_SERVED() do { if (::nbi::mailbox_serving()) return NBODY_ERR_STATE; } while (0)
 #define HIPC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { NB_MARK(); return (int)e_; } } while (0)
 #define NBC(expr) do { int e_ = (expr); if (e_ != NBODY_OK) return e_; } while (0)
 #define NCCLC(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { NB_MARK(); return 2000 + (int)r_; } } while (0)
@@ -111,6 +115,9 @@ struct Global {
   int cu_count = 0, clock_khz = 0;
   int comm_priority = 0;          // HIP priority of the transfer streams (0 = default)
   long long steps_done = 0;
+  // The CONTEXT's N and resolved configuration as nbody_get_info reports them: published by reconfigure(), never touched by a mailbox
+  // request (which switches the fields above for its own duration) — so the caller's thread may read them while the service thread works
+  struct View { int n = 0, n_local = 0, variant = 0, R = 0, sub = 0, nseg = 1, fuse = 1, wsplit = 1; } view;
 };
 extern Global g;
 
@@ -164,7 +171,9 @@ struct KernelSel {
 int launch_force_kernel(const KernelSel& k, hipStream_t stream, dim3 grid, const nbk::ForceArgs& a);
 int launch_combine_kernel(int fp64, hipStream_t stream, dim3 grid, const nbk::ForceArgs& a);
 int launch_drift_kernel(int fp64, hipStream_t stream, void* pos_rows, const void* vel, int n_rows, float dt, double dt64);
-int launch_ingest_kernel(hipStream_t stream, void* dst_words, const void* ram_a_bodies, int n);
+int launch_ingest_kernel(hipStream_t stream, void* dst_words, const void* ram_a_bodies, int n, unsigned long long* t0);
+int launch_mailbox_done_kernel(hipStream_t stream, void* word0, unsigned* seq_word, const unsigned long long* t0, unsigned seq,
+                               unsigned clock_khz, unsigned rt_khz);
 int launch_rsqrt_selftest_kernel(unsigned first_bits, unsigned long long count, unsigned long long* out3);
 int launch_rsqrt_array_kernel(const float* x, float* y, int n, int ieee_only);
 bool diag_build();   // this is libnbody_hip_diag.so (-DNBODY_DIAG_LOOPS): experiment encodings and timing-only loop forms present

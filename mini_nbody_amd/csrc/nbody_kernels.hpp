@@ -1105,9 +1105,28 @@ __global__ void __launch_bounds__(kBlock) combine_kernel(ForceArgs a) {
 // The mailbox's RAM A read port (S/top_level.vhd:206-208, 238-240): body words 1..N of the host's RAM image — pinned host memory
 // the device reads over PCIe — into the resident source array, one 16-byte word per lane.  A kernel rather than a copy command:
 // it sits on the same queue as the force launch that follows, so a request is launches only, with no hand-over between engines.
-__global__ void __launch_bounds__(kBlock) ingest_kernel(f4* dst, const f4* ram_a_bodies, int n) {
+// Its first wave also starts the request's tick counter (S/top_level.vhd:138-139: clk_ctr leaves 0 on BEGIN's rising edge): *t0 = the
+// constant-rate real-time counter (s_memrealtime, 100 MHz), read back by mailbox_done_kernel.
+__global__ void __launch_bounds__(kBlock) ingest_kernel(f4* dst, const f4* ram_a_bodies, int n, unsigned long long* t0) {
+  if (t0 && blockIdx.x == 0 && threadIdx.x == 0) *t0 = __builtin_amdgcn_s_memrealtime();
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) dst[i] = ram_a_bodies[i];
+}
+
+// `complete` (S/top_level.vhd:255-263) done by the device, as the PL block does it: the last launch of a request — one wave on the
+// same queue, behind the force pass that stored RAM B — rewrites word 0 of RAM A (pinned host memory) with {ticks in bits 63:32, 0
+// elsewhere}.  ticks = 1 + elapsed 1000-clock units of a `clock_khz` clock between the ingest kernel's first wave and this store
+// (:121-146), from the real-time counter (rt_khz, 100 MHz on gfx950).  BEGIN (bit 0) is cleared LAST and with system-scope release: whoever
+// reads BEGIN = 0 also reads the ticks and every word of RAM B.  After it, `seq` goes into a second pinned word that the PS never writes: the
+// library's own completion signal (the driver may raise BEGIN again the moment it has seen it fall).
+__global__ void __launch_bounds__(64) mailbox_done_kernel(unsigned* word0, unsigned* seq_word, const unsigned long long* t0, unsigned seq,
+                                                          unsigned clock_khz, unsigned rt_khz) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - *t0;          // in 1 / rt_khz ms
+  const unsigned long long ticks = 1ull + dt * clock_khz / ((unsigned long long)rt_khz * 1000ull);
+  word0[1] = (unsigned)(ticks > 0xFFFFFFFFull ? 0xFFFFFFFFull : ticks); word0[2] = 0u; word0[3] = 0u;
+  __hip_atomic_store(&word0[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // integrate(): r += v * dt for the rank's bodies, in place.

@@ -5,7 +5,7 @@
  *   write the bodies to words 1..N of RAM A        {x, y, z, ignored}, 16 bytes each     S/top_level.vhd:206-208
  *   write word 0 = {bit 0 BEGIN, bits 46:32 NUM_PTS}                                     S/top_level.vhd:184-185
  *   poll word 0 until BEGIN reads 0; bits 63:32 then hold the elapsed 1000-clock ticks   S/top_level.vhd:146, 255-263
- *   read the forces {Fx, Fy, Fz, 0} from words 0..N-1 of RAM B                           S/compute_store.vhd:213, 227-242
+ *   read the forces {Fx, Fy, Fz, 0} of bodies 1..N from words 1..N of RAM B (word 0 is never written)   S/compute_store.vhd:213, 221-242
  * ONE power-up, then any number of requests of any size (NUM_PTS is sampled per request, S/top_level.vhd:180-186).
  *
  * usage: mailbox_driver [--served] [--timed] [--seed S] N1 [N2 ...]
@@ -48,7 +48,7 @@ int main(int argc, char **argv) {
     const int n = sizes[r];
     if (n < 0 || n > capacity) { fprintf(stderr, "NUM_PTS %d is outside 0..%d\n", n, capacity); return 2; }
     if (n > 0) nbody_ic_fill_f32(pos, vel, (size_t)n, 0, (size_t)n, seed);
-    for (int k = 0; k < capacity * 4; ++k) ((uint32_t *)ram_b)[k] = 0xDEADBEEFu;   /* to show that words >= N are left alone */
+    for (int k = 0; k < (capacity + 1) * 4; ++k) ((uint32_t *)ram_b)[k] = 0xDEADBEEFu;   /* to show that word 0 and the words > N are left alone */
     memcpy(ram_a + 4, pos, (size_t)n * 16);                  /* bodies: words 1..N                  S/top_level.vhd:206-208 */
     ram_a[1] = (uint32_t)n; ram_a[2] = 0; ram_a[3] = 0;      /* NUM_PTS in bits [46:32]             S/top_level.vhd:185 */
     if (served) {
@@ -60,10 +60,11 @@ int main(int argc, char **argv) {
       CHECK(nbody_mailbox_run(ram_a, ram_b, /*clock_khz*/300000));
     }
     double cx = 0, cy = 0, cz = 0;
-    for (int i = 0; i < n; ++i) { cx += ram_b[4 * i]; cy += ram_b[4 * i + 1]; cz += ram_b[4 * i + 2]; }
+    for (int k = 1; k <= n; ++k) { cx += ram_b[4 * k]; cy += ram_b[4 * k + 1]; cz += ram_b[4 * k + 2]; }   /* force of body k: word k */
     int untouched = 1;
-    for (int k = n * 4; k < capacity * 4; ++k) untouched &= ((uint32_t *)ram_b)[k] == 0xDEADBEEFu;
-    printf("NUM_PTS %d  BEGIN %u  ticks %u  checksum (sum of forces): %.9g %.9g %.9g  RAM B beyond word N-1 untouched: %s\n",
+    for (int k = 0; k < 4; ++k) untouched &= ((uint32_t *)ram_b)[k] == 0xDEADBEEFu;
+    for (int k = (n + 1) * 4; k < (capacity + 1) * 4; ++k) untouched &= ((uint32_t *)ram_b)[k] == 0xDEADBEEFu;
+    printf("NUM_PTS %d  BEGIN %u  ticks %u  checksum (sum of forces): %.9g %.9g %.9g  RAM B word 0 and beyond word N untouched: %s\n",
            n, ram_a[0] & 1u, ram_a[1], cx, cy, cz, untouched ? "yes" : "NO");
   }
   free(pos); free(vel);

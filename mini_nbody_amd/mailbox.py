@@ -2,7 +2,8 @@
 
 RAM A: word 0 = control {bit 0 BEGIN, bits 46:32 NUM_PTS}        S/top_level.vhd:184-185
        words 1..N = {x, y, z, ignored}, 16 bytes each             S/top_level.vhd:206-208, 238-240
-RAM B: word k-1 = {Fx, Fy, Fz, 0} of body k                      S/compute_store.vhd:213, 227-242
+RAM B: word k = {Fx, Fy, Fz, 0} of body k (the index the body has in RAM A); word 0 is never written
+                                                                  S/compute_store.vhd:213, 221-242 (tests/test_fpga_store_model.py)
 done:  word 0 of RAM A <- {ticks in bits 63:32}, BEGIN reads 0    S/top_level.vhd:146, 255-263
        one tick = 1000 clocks                                     S/top_level.vhd:121-144
 max N = ram_depth - 1 = 32767                                     S/top_level.vhd:45
@@ -36,23 +37,25 @@ def decode_control(ram_a):
 
 
 def run(engine, ram_a, clock_khz=0, ram_b=None):
-    """Execute one request in place on the open context (`engine`: an NBody or a Mailbox): returns RAM B (N x 4 float32, or the
-    caller's own image `ram_b`, of which only words 0..N-1 are written) and rewrites word 0 of ram_a."""
+    """Execute one request in place on the open context (`engine`: an NBody or a Mailbox) and rewrite word 0 of ram_a.  `ram_b`: the
+    caller's own RAM B image of at least N + 1 words, of which only words 1..N are written (a fresh one if None).  Returns the forces
+    of bodies 1..N = words 1..N of RAM B, as a view."""
     ram_a = np.asarray(ram_a)
     assert ram_a.dtype == np.uint32 and ram_a.flags.c_contiguous
     n = decode_control(ram_a)["num_pts"]
     if ram_b is None:
-        ram_b = np.zeros((max(n, 1), 4), np.float32)[:n]
-    assert ram_b.dtype == np.float32 and ram_b.flags.c_contiguous and len(ram_b) >= n
+        ram_b = np.zeros((n + 1, 4), np.float32)
+    assert ram_b.dtype == np.float32 and ram_b.flags.c_contiguous and len(ram_b) >= n + 1
     L.check(engine.lib.nbody_mailbox_run(ram_a.ctypes.data_as(C.c_void_p), ram_b.ctypes.data_as(C.c_void_p), int(clock_khz)))
-    return ram_b
+    return ram_b[1:n + 1]
 
 
 class Mailbox:
     """The PL block as the PS sees it (nbody_mailbox_open): ONE context serving requests of any NUM_PTS in 0..capacity, NUM_PTS sampled
     with every BEGIN (S/top_level.vhd:180-186).  faithful=True: the RTL's own rounding points and summation order, bit for bit
     (granted only after the device has proved the strict 1/sqrt).  `ram_a` / `ram_b` are the context's own RAM images — pinned host
-    memory the device reads and writes directly — as numpy views: (capacity + 1, 4) uint32 and (capacity, 4) float32."""
+    memory the device reads and writes directly — as numpy views: (capacity + 1, 4) uint32 and (capacity + 1, 4) float32 (word 0 of RAM B
+    exists and is never written)."""
 
     def __init__(self, capacity=MAX_POINTS, faithful=True):
         self.lib = L.load()
@@ -62,7 +65,7 @@ class Mailbox:
         L.check(self.lib.nbody_mailbox_rams(C.byref(a), C.byref(b), C.byref(cap)))
         self.capacity, self.faithful, self._posted = cap.value, bool(faithful), 0
         self.ram_a = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_uint32)), shape=(self.capacity + 1, 4))
-        self.ram_b = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_float)), shape=(self.capacity, 4))
+        self.ram_b = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_float)), shape=(self.capacity + 1, 4))
 
     def post(self, pos):
         """What the PS does before it raises BEGIN: bodies into words 1..N of RAM A, NUM_PTS and BEGIN into word 0."""
@@ -77,10 +80,10 @@ class Mailbox:
         return n
 
     def run(self, clock_khz=0):
-        """One request on the context's own RAMs (no host copy): returns (view of RAM B words 0..N-1, ticks)."""
+        """One request on the context's own RAMs (no host copy): returns (view of RAM B words 1..N = the forces of bodies 1..N, ticks)."""
         n = int(self.ram_a[0, 1] & 0x7FFF)
         L.check(self.lib.nbody_mailbox_run(self.ram_a.ctypes.data_as(C.c_void_p), self.ram_b.ctypes.data_as(C.c_void_p), int(clock_khz)))
-        return self.ram_b[:n], int(self.ram_a[0, 1])
+        return self.ram_b[1:n + 1], int(self.ram_a[0, 1])
 
     def forces(self, pos, clock_khz=0):
         """post + run; the result is a copy."""
@@ -95,7 +98,7 @@ class Mailbox:
         self._serving = bool(on)
 
     def wait(self, timeout=10.0):
-        """What the PS does after raising BEGIN: poll word 0 of RAM A until BEGIN reads 0.  Returns (RAM B words 0..N-1 (view), ticks);
+        """What the PS does after raising BEGIN: poll word 0 of RAM A until BEGIN reads 0.  Returns (RAM B words 1..N (view), ticks);
         raises if the library flagged the request (bits 127:96 of word 0, which the RTL always writes as 0)."""
         import time
         n = self._posted                       # (word 0 may already hold the tick count: NUM_PTS is what post() wrote)
@@ -106,7 +109,7 @@ class Mailbox:
                 raise TimeoutError("the mailbox did not complete within %.1f s" % timeout)
         if int(w0[3]):
             raise L.NBodyError(int(w0[3]), "mailbox request refused: " + self.lib.nbody_error_string(int(w0[3])).decode())
-        return self.ram_b[:n], int(w0[1])
+        return self.ram_b[1:n + 1], int(w0[1])
 
     def served(self):
         v = C.c_longlong()

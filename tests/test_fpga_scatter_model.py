@@ -17,71 +17,7 @@ import pytest
 
 import oracle as O
 
-FMA_LATENCY = 16     # S/top_level.vhd:40
-ZERO = ()            # symbolic 0.0: the empty sum
-
-
-class FxyzControl:
-    """One axis of S/fxyz.vhd:120-184.  step() is one clock: combinational signals from the registers' current values,
-    then the rising edge.  `fma` maps (a_item, c_value) -> value; the default builds the tuple of summed items."""
-
-    def __init__(self, latency=FMA_LATENCY, fma=None):
-        self.L = latency
-        self.pipe = [(0, None)] * latency        # the fma IP: pipe[-1] is on m_axis_result this cycle         :120-127
-        self.flush_cnt = latency                 # signal FLUSH_CNT ... := fma_latency                          :86
-        self.scttr_cnt = 0                       # signal SCTTR_CNT ... := 0                                    :87
-        self.valid_prev = 0                      # VALID_FMA_PREV                                               :79
-        self.results = ["U"] * latency           # results(0 .. fma_latency - 1) of this axis, 'U' until written
-        self.fma = fma or (lambda item, c: c + (item,))
-        self.scatter_complete = 0
-
-    def step(self, valid_fma, item=None):
-        L = self.L
-        valid_fx, fx_out = self.pipe[-1]
-        flush_actv = valid_fma == 0 or self.flush_cnt != 0                                                   # :142
-        fx_in = ZERO if flush_actv else fx_out                                                                # :143
-        scttr_actv = (valid_fma == 0 and self.valid_prev == 1 and self.scttr_cnt == 0) or self.scttr_cnt != 0  # :167
-        # ---- rising edge ----
-        if valid_fma:
-            assert fx_in is not None, "the feedback mux selected an fma output that carries no item"
-            entering = (1, self.fma(item, fx_in))
-        else:
-            entering = (0, None)
-        if valid_fma == 0:                                                                                    # :133-137
-            flush_next = L
-        elif self.flush_cnt != 0:
-            flush_next = self.flush_cnt - 1
-        else:
-            flush_next = self.flush_cnt
-        scttr_next = self.scttr_cnt
-        if scttr_actv:                                                                                        # :150-156, :172-182
-            self.results[self.scttr_cnt] = fx_out if valid_fx else ZERO
-            scttr_next = 0 if self.scttr_cnt == L - 1 else self.scttr_cnt + 1
-        self.scatter_complete = 1 if self.scttr_cnt == L - 1 else 0                                           # :191-195
-        self.valid_prev = valid_fma                                                                           # :163
-        self.pipe = [entering] + self.pipe[:-1]
-        self.flush_cnt, self.scttr_cnt = flush_next, scttr_next
-
-    def run_stream(self, n, idle_before=3, first_item=0):
-        """the sequencer's compute state: n items on consecutive clocks (S/top_level.vhd:233-254), then idle until the
-        scatter is over (the FSM waits for STORE_BUSY, S/top_level.vhd:193)"""
-        for _ in range(idle_before):
-            self.step(0)
-        for k in range(n):
-            self.step(1, first_item + k)
-        done = 0
-        for _ in range(4 * self.L):
-            self.step(0)
-            done |= self.scatter_complete
-        assert done and self.scttr_cnt == 0
-        return list(self.results)
-
-
-def expected_slot(n, t, L=FMA_LATENCY, first_item=0):
-    k = n - L + t                      # the item whose fma output is on the bus when results(t) is latched
-    if k < 0:
-        return ZERO
-    return tuple(first_item + j for j in range(k % L, k + 1, L))
+from rtl_model import FMA_LATENCY, ZERO, FxyzControl, expected_slot     # the cycle model of S/fxyz.vhd:129-184 (tests/rtl_model.py)
 
 
 @pytest.mark.parametrize("n", list(range(1, 41)) + [47, 48, 49, 100, 257])

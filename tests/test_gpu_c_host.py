@@ -79,8 +79,8 @@ def test_ps_side_mailbox_driver_in_c(nb, oracle_fast, mode):
     """mini_nbody_amd/host/mailbox_driver.c — the PS-side driver INTEGRATION.md §1 shows, as a compiled C program over the C-ABI: ONE
     power-up, then requests of several sizes incl. the RTL's maximum and an empty one, called (nbody_mailbox_run) or served (the driver
     only writes RAM A and polls word 0).  Its force checksums must be the oracle's in the RTL-faithful mode (bit-exact forces, so the
-    double-precision sums agree to the last printed digit), within 1e-5 in the timed arithmetic; BEGIN cleared, ticks >= 1, RAM B
-    untouched from word N on."""
+    double-precision sums agree to the last printed digit), within 1e-5 in the timed arithmetic; BEGIN cleared, ticks >= 1, the force of body k at
+    word k of RAM B, word 0 and the words beyond N untouched (S/compute_store.vhd:221-242)."""
     import oracle as O
     exe = os.path.join(ROOT, "build", "mailbox_driver")
     if not os.path.exists(exe):
@@ -91,7 +91,7 @@ def test_ps_side_mailbox_driver_in_c(nb, oracle_fast, mode):
     lines = [l for l in out.stdout.splitlines() if l.startswith("NUM_PTS")]
     assert len(lines) == len(sizes), out.stdout
     for n, line in zip(sizes, lines):
-        m = re.match(r"NUM_PTS (\d+)  BEGIN (\d)  ticks (\d+)  checksum \(sum of forces\): (\S+) (\S+) (\S+)  RAM B beyond word N-1 untouched: (\w+)", line)
+        m = re.match(r"NUM_PTS (\d+)  BEGIN (\d)  ticks (\d+)  checksum \(sum of forces\): (\S+) (\S+) (\S+)  RAM B word 0 and beyond word N untouched: (\w+)", line)
         assert m, line
         assert int(m.group(1)) == n and m.group(2) == "0" and int(m.group(3)) >= 1 and m.group(7) == "yes", line
         got = np.array([float(m.group(k)) for k in (4, 5, 6)])

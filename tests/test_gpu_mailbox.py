@@ -1,13 +1,16 @@
 """The reference's ONLY interface — the memory-mapped mailbox — as one long-lived context:
 NUM_PTS sampled with every BEGIN (S/top_level.vhd:180-186) against RAMs sized once (:45), N = 0 completing at once with RAM B
-untouched (:189-192), words >= N of RAM B never written (S/compute_store.vhd:227-232), word 0 rewritten with the tick count and
-BEGIN = 0 (S/top_level.vhd:146, 255-263).  All through the C-ABI (nbody_mailbox_open / _rams / _run)."""
+untouched (:189-192), the force of body k at word k of RAM B, word 0 and the words beyond N never written (S/compute_store.vhd:221-242;
+the cycle model: tests/test_fpga_store_model.py), word 0 of RAM A rewritten with the tick count and BEGIN = 0 (S/top_level.vhd:146,
+255-263) — by the device itself.  All through the C-ABI (nbody_mailbox_open / _rams / _run / _serve)."""
 import ctypes as C
 import glob
 import json
 import os
 import subprocess
 import sys
+import threading
+import time
 
 import numpy as np
 import pytest
@@ -33,6 +36,12 @@ def fixture(n):
     return words("pos0"), words("forces0")
 
 
+def untouched(ram_b, n):
+    """word 0 of RAM B and every word beyond N still hold the sentinel: S/compute_store.vhd:221-242 never writes them"""
+    w = ram_b.view(np.uint32)
+    return bool(np.all(w[0] == SENTINEL) and np.all(w[n + 1:] == SENTINEL))
+
+
 def rtl_oracle(ora, rows, src):
     """the RTL's rounding points, 1/sqrt rounded once, sixteen partial sums + rotation + tree over ONE stream of all N"""
     return ora.forces_f32(rows, src, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64, summ=O.SUM_FPGA16)
@@ -41,11 +50,12 @@ def rtl_oracle(ora, rows, src):
 def test_one_context_serves_every_num_pts_bit_for_bit(nb, oracle_fast):
     """ONE faithful context of the RTL's capacity replays rtl_n9 -> rtl_n100 -> rtl_n40 (exact-rational third statements of the RTL,
     tests/golden/make_system.py) -> N = 32767 (row samples against the oracle) -> N = 0 -> rtl_n9 again, on the context's own RAMs
-    (no host copy) — every RAM B image bit for bit, and every word of RAM B from word N on left exactly as it was."""
+    (no host copy) — every RAM B image bit for bit at words 1..N, word 0 and every word beyond N left exactly as they were; the tick
+    word is the DEVICE's count of the request (ingest kernel's first wave to the store of word 0), not the host's latency."""
     big = nb.mailbox.MAX_POINTS
     pos_big, _ = nb.make_bodies(big, seed=12)
     with nb.Mailbox() as mb:                                   # capacity 32767 = ram_depth - 1, faithful
-        assert mb.capacity == big and mb.ram_a.shape == (big + 1, 4) and mb.ram_b.shape == (big, 4)
+        assert mb.capacity == big and mb.ram_a.shape == (big + 1, 4) and mb.ram_b.shape == (big + 1, 4)
         for n in (9, 100, 40, big, 0, 9):
             mb.ram_b.view(np.uint32)[...] = SENTINEL
             pos = pos_big if n == big else (np.zeros((0, 4), np.float32) if n == 0 else fixture(n)[0])
@@ -55,29 +65,32 @@ def test_one_context_serves_every_num_pts_bit_for_bit(nb, oracle_fast):
             ctl = nb.mailbox.decode_control(mb.ram_a)
             assert ctl["begin"] == 0 and ctl["ticks"] == ticks >= 1                 # S/top_level.vhd:146, 255-263
             assert np.all(mb.ram_a[0, [0, 2, 3]] == 0)                              # {ticks in 63:32, 0 elsewhere}
-            assert np.all(mb.ram_b.view(np.uint32)[n:] == SENTINEL), n             # S/compute_store.vhd:227-232
+            assert untouched(mb.ram_b, n), n                                        # S/compute_store.vhd:221-242
             if n == 0:
                 assert ticks <= 2                                                   # straight to `complete`, S/top_level.vhd:189-192
             elif n == big:
                 rows = np.r_[0:64, n // 2:n // 2 + 64, n - 64:n]
                 assert np.array_equal(bits(out[rows]), bits(rtl_oracle(oracle_fast, pos[rows], pos)))
                 assert np.all(out[:, 3] == 0)
+                assert 30 < ticks < 3000                                            # ~0.5 ms of device time at 300 MHz = ~150 ticks
             else:
                 assert np.array_equal(bits(out), bits(fixture(n)[1])), n
                 assert np.all(out[:, 3] == 0)                                       # {Fx, Fy, Fz, 0}, S/compute_store.vhd:242
+                assert ticks <= 30                                                  # < 100 us of DEVICE time (the host's 20 us of latency would be 7)
 
 
 def test_callers_own_ram_images(nb):
-    """Any host buffers do as RAM A / RAM B (one host copy each way): same bits, and the caller's RAM B beyond word N-1 is untouched."""
+    """Any host buffers do as RAM A / RAM B (one host copy each way): same bits at words 1..N, and the caller's RAM B word 0 and beyond
+    word N is untouched."""
     with nb.Mailbox(capacity=128) as mb:
-        ram_b = np.full((128, 4), SENTINEL, np.uint32).view(np.float32)
+        ram_b = np.full((129, 4), SENTINEL, np.uint32).view(np.float32)
         for n in (100, 9, 0, 40):
             ram_b.view(np.uint32)[...] = SENTINEL
             pos = fixture(n)[0] if n else np.zeros((0, 4), np.float32)
             ram_a = nb.mailbox.encode_request(pos)
             out = nb.mailbox.run(mb, ram_a, clock_khz=300000, ram_b=ram_b)
             assert nb.mailbox.decode_control(ram_a)["begin"] == 0
-            assert np.all(ram_b.view(np.uint32)[n:] == SENTINEL)
+            assert untouched(ram_b, n)
             if n:
                 assert np.array_equal(bits(out[:n]), bits(fixture(n)[1]))
 
@@ -257,7 +270,7 @@ def test_served_mailbox_needs_no_call_per_request(nb, oracle_fast):
                     out, ticks = mb.wait()
                     count += 1
                     assert ticks >= 1 and np.all(mb.ram_a[0, [0, 2, 3]] == 0)
-                    assert np.all(mb.ram_b.view(np.uint32)[n:] == SENTINEL), n
+                    assert untouched(mb.ram_b, n), n
                     if n:
                         assert np.array_equal(bits(out), bits(called[n])) and np.array_equal(bits(out), bits(fixture(n)[1])), n
             big, _ = nb.make_bodies(2048, seed=3)
@@ -270,6 +283,10 @@ def test_served_mailbox_needs_no_call_per_request(nb, oracle_fast):
                 mb.wait()
             count += 1
             assert e.value.code == nb._lib.ERR_ARG and mb.ram_a[0, 0] == 0 and mb.ram_a[0, 1] == 0
+            for _ in range(1000):                                  # (the device clears BEGIN itself; the thread's counter follows within microseconds)
+                if mb.served() - before == count:
+                    break
+                time.sleep(0.001)
             assert mb.served() - before == count
         finally:
             mb.serve(False)
@@ -280,3 +297,84 @@ def test_served_mailbox_needs_no_call_per_request(nb, oracle_fast):
     mb.post(fixture(9)[0])
     mb.wait()
     mb.close()
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+def test_num_pts_1_2_3_are_answered_a_stated_departure_from_the_rtl(nb, oracle_fast, faithful):
+    """The RTL as written never raises TRGT_VALID for NUM_PTS <= uram_latency = 3 (S/top_level.vhd:42, 234-254; the cycle model:
+    tests/test_fpga_fsm_model.py test_i_*): the pass completes with RAM B untouched.  That is a defect of the sequencer, not protocol; the
+    library computes the forces for 1, 2 and 3 bodies like for any other N ("Departures from the RTL as written")."""
+    pos, _ = nb.make_bodies(3, seed=9)
+    with nb.Mailbox(capacity=64, faithful=faithful) as mb:
+        for n in (1, 2, 3):
+            mb.ram_b.view(np.uint32)[...] = SENTINEL
+            mb.post(pos[:n])
+            out, ticks = mb.run(300000)
+            assert ticks >= 1 and mb.ram_a[0, 0] == 0 and untouched(mb.ram_b, n)
+            want = rtl_oracle(oracle_fast, pos[:n], pos[:n])
+            if faithful:
+                assert np.array_equal(bits(out), bits(want)), n
+            else:
+                assert np.abs(out[:, :3].astype(np.float64) - want[:, :3]).max() <= 1e-5 * max(1e-30, np.abs(want[:, :3]).max()), n
+            if n == 1:
+                assert np.all(out == 0)                                             # one body: only the self pair, exactly zero force
+
+
+def test_the_served_context_is_guarded_against_the_callers_thread(nb):
+    """While nbody_mailbox_serve(1, .) is in effect the service thread owns the context: every entry point that
+    launches, copies or reconfigures answers NBODY_ERR_STATE, and nbody_get_info reports the CONTEXT's N and configuration — never the N a
+    request has switched in for its own duration.  A second thread hammers both while 10^4 served requests of alternating sizes stay
+    bit-exact."""
+    L = nb._lib
+    lib = L.load()
+    cap = 1024
+    pos_all, _ = nb.make_bodies(cap, seed=21)
+    sizes = (9, 700, 40, 100, 1, 333)
+    with nb.Mailbox(capacity=cap, faithful=True) as mb:
+        first = {n: mb.forces(pos_all[:n]) for n in sizes}
+        cfg0 = {k: C.c_longlong() for k in (L.INFO_N, L.INFO_N_LOCAL, L.INFO_NSEG, L.INFO_JSUB, L.INFO_WSPLIT, L.INFO_VARIANT, L.INFO_FUSE_COMBINE)}
+        for k, v in cfg0.items():
+            assert lib.nbody_get_info(k, C.byref(v)) == 0
+        assert cfg0[L.INFO_N].value == cap
+        mb.serve(True, 300000)
+        stop, seen = threading.Event(), {"info": 0, "refused": 0, "bad": []}
+        buf = np.zeros((cap, 4), np.float32)
+        bs = L.BodySystem(buf.ctypes.data_as(C.POINTER(C.c_float)), buf.ctypes.data_as(C.POINTER(C.c_float)))
+
+        def hammer():
+            v = C.c_longlong()
+            refused = [lambda: lib.nbody_step(C.c_float(0.01), 1), lambda: lib.nbody_set_option(L.OPT_JSUB, 2), lambda: lib.nbody_upload(C.byref(bs)),
+                       lambda: lib.nbody_download(C.byref(bs)), lambda: lib.nbody_forces(buf.ctypes.data_as(C.POINTER(C.c_float)), buf.ctypes.data_as(C.POINTER(C.c_float)), cap),
+                       lambda: lib.bodyForce(buf.ctypes.data_as(C.POINTER(C.c_float)), buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(0.01), cap),
+                       lambda: lib.nbody_sync(), lambda: lib.nbody_mailbox_open(64, 0), lambda: lib.nbody_init(64, 1, 0, 0),
+                       lambda: lib.nbody_mailbox_run(mb.ram_a.ctypes.data_as(C.c_void_p), mb.ram_b.ctypes.data_as(C.c_void_p), 0)]
+            k = 0
+            while not stop.is_set():
+                for key, want in cfg0.items():
+                    rc = lib.nbody_get_info(key, C.byref(v))
+                    if rc != 0 or v.value != want.value:
+                        seen["bad"].append(("info", key, rc, v.value, want.value))
+                    seen["info"] += 1
+                rc = refused[k % len(refused)]()
+                if rc != L.ERR_STATE:
+                    seen["bad"].append(("call", k % len(refused), rc))
+                seen["refused"] += 1
+                k += 1
+
+        th = threading.Thread(target=hammer)
+        th.start()
+        try:
+            for k in range(10000):
+                n = sizes[k % len(sizes)]
+                mb.post(pos_all[:n])
+                out, ticks = mb.wait()
+                if ticks < 1 or not np.array_equal(bits(out), bits(first[n])):
+                    raise AssertionError("served request %d (N = %d) differs from the called form" % (k, n))
+        finally:
+            stop.set()
+            th.join()
+            mb.serve(False)
+        assert not seen["bad"], seen["bad"][:5]
+        assert seen["info"] > 1000 and seen["refused"] > 100, seen
+        # ... and the context is the caller's again
+        assert lib.nbody_sync() == 0 and np.array_equal(bits(mb.forces(pos_all[:40])), bits(first[40]))

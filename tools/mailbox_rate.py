@@ -58,7 +58,7 @@ def main():
                 us_own = per_call_us(own, args.calls)
                 ticks = int(mb.ram_a[0, 1])
                 ram_a = nb.mailbox.encode_request(pos)
-                ram_b = np.zeros((n, 4), np.float32)
+                ram_b = np.zeros((n + 1, 4), np.float32)
                 a_any, b_any = ram_a.ctypes.data_as(vp), ram_b.ctypes.data_as(vp)
 
                 def anyb():
@@ -67,7 +67,7 @@ def main():
                     rc = run(a_any, b_any, 300000)
                     assert rc == 0, rc
                 us_any = per_call_us(anyb, args.calls)
-                assert np.array_equal(ram_b.view(np.uint32), mb.ram_b[:n].view(np.uint32))
+                assert np.array_equal(ram_b[1:].view(np.uint32), mb.ram_b[1:n + 1].view(np.uint32))
                 mb.serve(True, 300000)
                 w0 = mb.ram_a[0]
 
@@ -78,7 +78,7 @@ def main():
                         pass
                 us_srv = per_call_us(served, args.calls)
                 mb.serve(False)
-                assert np.array_equal(ram_b.view(np.uint32), mb.ram_b[:n].view(np.uint32)) and int(w0[3]) == 0
+                assert np.array_equal(ram_b[1:].view(np.uint32), mb.ram_b[1:n + 1].view(np.uint32)) and int(w0[3]) == 0
                 print("N = %5d  %-44s own RAMs %8.1f us  any buffers %8.1f us  served %8.1f us  (%7.1f G pairs/s; ticks word %d)   RTL estimate %10.1f us = %6.0fx" %
                       (n, name, us_own, us_any, us_srv, float(n) * n / us_own / 1e3, ticks, rtl_us, rtl_us / us_own))
 

@@ -2,7 +2,7 @@
 """Soak of the mailbox (nbody_mailbox_open / _run / _serve) on the GPU box: for --seconds seconds, requests of random size (0..capacity,
 small sizes favoured) through a random form — called on the context's own RAMs, called on the caller's buffers, served by the library's
 thread — every answer compared bit for bit with the first answer for that size (and, for the sizes of the exact-rational fixtures, with
-the fixture), a sentinel pattern in RAM B checked from word N on, the service thread switched on and off between bursts.
+the fixture), a sentinel pattern in RAM B checked at word 0 and beyond word N, the service thread switched on and off between bursts.
 usage: python tools/mailbox_soak.py [--seconds 20] [--capacity 4096] [--timed]"""
 import argparse
 import glob
@@ -36,7 +36,7 @@ def main():
     sentinel = np.uint32(0xDEADBEEF)
     t_end = time.time() + args.seconds
     with nb.Mailbox(capacity=args.capacity, faithful=not args.timed) as mb:
-        ram_b_any = np.empty((args.capacity, 4), np.float32)
+        ram_b_any = np.empty((args.capacity + 1, 4), np.float32)
         serving = False
         while time.time() < t_end:
             if rng.random() < 0.02:                       # switch the service thread on / off
@@ -49,13 +49,15 @@ def main():
             form = "served" if serving else ("own" if rng.random() < 0.5 else "any")
             if form == "any":
                 ram_b_any.view(np.uint32)[...] = sentinel
-                out = nb.mailbox.run(mb, nb.mailbox.encode_request(pos), clock_khz=300000, ram_b=ram_b_any)[:n]
-                tail_ok = bool(np.all(ram_b_any.view(np.uint32)[n:] == sentinel))
+                out = nb.mailbox.run(mb, nb.mailbox.encode_request(pos), clock_khz=300000, ram_b=ram_b_any)
+                rb = ram_b_any.view(np.uint32)
+                tail_ok = bool(np.all(rb[0] == sentinel) and np.all(rb[n + 1:] == sentinel))
             else:
                 mb.ram_b.view(np.uint32)[...] = sentinel
                 mb.post(pos)
                 out, ticks = mb.wait() if serving else mb.run(300000)
-                tail_ok = bool(np.all(mb.ram_b.view(np.uint32)[n:] == sentinel)) and ticks >= 1 and int(mb.ram_a[0, 0]) == 0
+                rb = mb.ram_b.view(np.uint32)
+                tail_ok = bool(np.all(rb[0] == sentinel) and np.all(rb[n + 1:] == sentinel)) and ticks >= 1 and int(mb.ram_a[0, 0]) == 0
             got = out.view(np.uint32).copy()
             if key not in first:
                 first[key] = got
@@ -69,7 +71,7 @@ def main():
             mb.serve(False)
         served = mb.served()
     print("mailbox soak: %d requests in %.0f s (%s arithmetic, capacity %d): %d distinct sizes, by form %s, %d completed by the service thread — "
-          "every RAM B image bit-identical to the size's first, fixtures reproduced, RAM B untouched from word N on, BEGIN cleared, ticks >= 1"
+          "every RAM B image bit-identical to the size's first, fixtures reproduced, RAM B word 0 and the words beyond N untouched, BEGIN cleared, ticks >= 1"
           % (count, args.seconds, "timed" if args.timed else "RTL-faithful", args.capacity, len(first), by_form, served))
 
 
