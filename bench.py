@@ -54,7 +54,7 @@ prints the headline line — complete, cpu_baseline included — BEFORE any stud
   configs       (the default line only) the other BASELINE configurations one GPU reaches, each {value, ms_per_step, frac}: config2 (N = 65536,
                 100 steps: the engine's default and --variant lds --tile 256), fp64 (N = 262144, 3 steps, frac against 78.6 TFLOP/s and
                 of the issue bound), config1 (N = 4096, 10 iterations: oracle/nbody_cpu beside build/nbody --strict, same checksum line);
-                at most --configs-budget (15) seconds.
+                at most --configs-budget (40) seconds; every entry carries its own cpu_baseline (a <= 3-s row sample at its N and precision).
 and the parent prints the LAST complete line: a study kernel that faults or hangs costs neither the headline nor the passes before it
 ("extras" then says what happened).
 and for N > 1: comm_exposed_ms_per_step — how long per step the compute stream sat waiting for arriving position slices
@@ -89,11 +89,14 @@ METRIC = "billion pair-interactions/s at N=1M fp32; 1/2/4/8 GPUs + % FP32 roofli
 COMM_NAMES = {0: "ring", 1: "allgather", 2: "auto", 3: "direct"}
 
 
-def cpu_baseline(n, seed, fp64, target_s=15.0):
-    """The oracle timed on the host cores: a row sample (first rows x all N sources), sized to take
-    roughly target_s seconds (15 at N = 1; 3 on an N > 1 line, where the other ranks wait at a barrier).  Returns the JSON object."""
+_CPU_ORACLE = {}      # the host build of the oracle, made once per process (the configs entries time their own samples with it)
+
+
+def cpu_oracle():
+    """(Oracle, its library path or None, its thread count): oracle/nbody_ref.c built for THIS host — the cpu_baseline legs' checker-turned-baseline"""
+    if _CPU_ORACLE:
+        return _CPU_ORACLE["ora"], _CPU_ORACLE["path"], _CPU_ORACLE["cores"]
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     import oracle as O
     path = None
     # same source, tuned for this host if the compiler is here (falls back to the prebuilt x86-64-v3 build)
@@ -112,7 +115,17 @@ def cpu_baseline(n, seed, fp64, target_s=15.0):
         ora.set_num_threads(len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         pass
-    cores = ora.num_threads()
+    _CPU_ORACLE.update(ora=ora, path=path, cores=ora.num_threads())
+    return ora, path, _CPU_ORACLE["cores"]
+
+
+def cpu_baseline(n, seed, fp64, target_s=15.0):
+    """The oracle timed on the host cores: a row sample (first rows x all N sources), sized to take
+    roughly target_s seconds (15 at N = 1; 3 on an N > 1 line, where the other ranks wait at a barrier, and per `configs` entry).
+    Returns the JSON object."""
+    import numpy as np
+    ora, path, cores = cpu_oracle()
+    import oracle as O
     import mini_nbody_amd as nb
     pos, _ = nb.make_bodies(n, seed=seed, dtype=np.float64 if fp64 else np.float32)
 
@@ -682,7 +695,7 @@ def main(argv=None):
     ap.add_argument("--configs-pass", choices=["auto", "never"], default="auto",
                     help="auto: a default one-GPU fp32 line (N = 1,048,576, timed arithmetic) also carries `configs` — BASELINE configs 1 and 2 and "
                          "the fp64 arithmetic, measured after the headline line is out, at most --configs-budget seconds")
-    ap.add_argument("--configs-budget", type=float, default=15.0)
+    ap.add_argument("--configs-budget", type=float, default=40.0)
     ap.add_argument("--config5-bodies", type=int, default=4194304, help="bodies of the extras pass's fp64 run (BASELINE configs[4]: 4,194,304)")
     args = ap.parse_args(argv)
     code = supervisor_main(args, argv)
@@ -983,11 +996,27 @@ def configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, budget_s):
                 res[key] = {"value": None, "error": repr(ex)}
         publish("configs", dict(res))
 
-    def config2(variant, tile):
+    cpu_cache = {}
+
+    def cpu_leg(n_, fp64_):
+        """this entry's own host-CPU column: a <= 3-s row sample at the entry's N and precision (entries of one N and precision share it)"""
+        key = (n_, bool(fp64_))
+        if key not in cpu_cache:
+            try:
+                cpu_cache[key] = cpu_baseline(n_, args.seed, fp64_, 3.0)
+            except Exception as ex:
+                cpu_cache[key] = {"value": None, "unit": "billion pair-interactions/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+        return cpu_cache[key]
+
+    def config2(variant, tile, iblock=0, jsub=0):
         def make():
             n2, steps = 65536, 100
             with nb.NBody(n2, tile=tile) as e:
                 e.set_option(nb.OPT_VARIANT, variant)
+                if iblock:
+                    e.set_option(nb.OPT_IBLOCK, iblock)
+                if jsub:
+                    e.set_option(nb.OPT_JSUB, jsub)
                 pos, vel = nb.make_bodies(n2, seed=args.seed)
                 e.upload(pos, vel)
                 r = run_timed(e, steps, 50, False)      # 50 untimed steps (~50 ms): clocks up after the engine switch
@@ -995,7 +1024,11 @@ def configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, budget_s):
                 value = float(n2) * n2 * steps / r["elapsed"] / 1e9
                 return {"workload": "N=%d fp32, %d steps, 1 GPU" % (n2, steps), "value": round(value, 2), "unit": "billion pair-interactions/s",
                         "ms_per_step": round(1e3 * r["elapsed"] / steps, 4), "frac": round(value * FLOP_PER_PAIR / 1e3 / PEAK_VECTOR_TFLOPS["f32"], 4),
-                        "kernel": {k: cfg[k] for k in ("variant", "tile", "iblock", "nseg", "wsplit", "launches_per_step")}}
+                        "kernel": {k: cfg[k] for k in ("variant", "tile", "iblock", "nseg", "wsplit", "launches_per_step")},
+                        "form": ("the engine's default" if variant == nb.VARIANT_AUTO else
+                                 "the north_star's form — sources tiled into LDS, tile %d — in its best measured shape: %d bodies per lane, %d segments "
+                                 "(profiles/r05_sweep_lds_n65536.txt)" % (tile, iblock, jsub)),
+                        "cpu_baseline": cpu_leg(n2, False)}
         return make
 
     def fp64():
@@ -1010,7 +1043,8 @@ def configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, budget_s):
             return {"workload": "N=%d fp64, %d steps, 1 GPU" % (n5, steps), "value": round(value, 2), "unit": "billion pair-interactions/s",
                     "ms_per_step": round(1e3 * r["elapsed"] / steps, 3), "frac": roof["frac"], "peak_tflops": roof["peak"],
                     "frac_of_issue_bound": roof["frac_of_issue_bound"], "kernel_ms_avg": roof["kernel_ms_avg"],
-                    "kernel": {k: cfg[k] for k in ("variant", "nseg", "wsplit", "launches_per_step")}}
+                    "kernel": {k: cfg[k] for k in ("variant", "nseg", "wsplit", "launches_per_step")},
+                    "cpu_baseline": cpu_leg(n5, True)}
 
     def config1():
         import re
@@ -1046,7 +1080,7 @@ def configs_pass(nb, args, np, dt, run_timed, roofline_of, publish, budget_s):
                 "checksums_equal": bool(g_chk and g_chk == c_chk and s_g_chk and s_g_chk == s_c_chk)}
 
     entry("config2", config2(nb.VARIANT_AUTO, 0))
-    entry("config2_lds_tile256", config2(nb.VARIANT_LDS, 256))
+    entry("config2_lds_tile256", config2(nb.VARIANT_LDS, 256, iblock=4, jsub=32))
     entry("fp64", fp64)
     entry("config1", config1)
     res["seconds"] = round(time.perf_counter() - t0, 2)

@@ -304,10 +304,11 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   // (r03, wall clock per step: 16384 waves in the launch (N = 16384) 68.0 us with the long buffers against 69.5, 20480 waves
   //  101.7 / 102.9, 24576 waves 144.2 / 142.2, 32768 waves 249.6 / 246.6: the switch sits at 88 waves per CU)
   a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y * (wg_threads(a.wsplit) / 64) < 88LL * cus ? 1 : 0) : g.opt.long_buffers;
-  nbl::KernelSel sel = {g.fp64, g.variant, R, g.opt.arith, g.tile, g.opt.isa_phase, 0};
+  nbl::KernelSel sel = {g.fp64, g.variant, R, g.opt.arith, g.tile, g.opt.isa_phase, g.opt.variant != NBODY_VARIANT_SMEM ? 1 : 0, 0};
   // optional occupancy cap: k workgroups (= k waves per SIMD) per CU by giving each 160 KiB / k of dynamic LDS
   if (g.opt.waves_per_simd > 0 && g.opt.waves_per_simd < 8) {
-    const size_t static_lds = (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0) + (a.wsplit > 1 ? (size_t)(a.wsplit - 1) * 64 * word_bytes() : 0);
+    const size_t static_lds = (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0) + (a.wsplit > 1 ? (size_t)(a.wsplit - 1) * 64 * word_bytes() : 0) +
+                              ((a.fpga16 && a.wsplit == 16 && sel.fpga_lds) ? (size_t)32 * 1024 : 0);
     // (a workgroup of WS waves holds WS / 4 wave slots per SIMD: the cap is on workgroups per CU = waves_per_simd / (WS / 4))
     const size_t budget = (size_t)(160 * 1024) / (size_t)g.opt.waves_per_simd;
     if (static_lds + 512 > budget) return NBODY_ERR_ARG;   // the kernel's own LDS (16-wave fp64 join: 30 KiB) already exceeds that share: no such cap exists

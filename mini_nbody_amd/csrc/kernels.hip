@@ -105,6 +105,14 @@ NBL_HIDDEN int launch_force_kernel(const KernelSel& s, hipStream_t st, dim3 grid
       default: return launch_k(force_smem_f64<4, 1>, s, st, grid, a);
     }
   }
+  if (a.fpga16 && a.wsplit == 16 && s.fpga_lds) {   // sources staged through LDS (the default of the sixteen-wave form)
+    switch (s.arith) {
+      case NBODY_ARITH_REFERENCE: return launch_k(force_fpga16w_lds_f32<1>, s, st, grid, a);
+      case NBODY_ARITH_STRICT: return launch_k(force_fpga16w_lds_f32<2>, s, st, grid, a);
+      case NBODY_ARITH_REFERENCE_STRICT: return launch_k(force_fpga16w_lds_f32<3>, s, st, grid, a);
+      default: return launch_k(force_fpga16w_lds_f32<0>, s, st, grid, a);
+    }
+  }
   if (a.fpga16 && a.wsplit == 16) {
     switch (s.arith) {
       case NBODY_ARITH_REFERENCE: return launch_k(force_fpga16w_f32<1>, s, st, grid, a);

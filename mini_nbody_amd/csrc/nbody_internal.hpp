@@ -165,6 +165,7 @@ namespace nbl {
 // which instantiation of the force kernel a launch takes (the rest travels in ForceArgs: wsplit, fpga16, long_buffers)
 struct KernelSel {
   int fp64, variant, R, arith, tile, isa_phase;
+  int fpga_lds;     // the FPGA order on sixteen waves: 1 = sources staged through LDS (default), 0 = scalar delivery (NBODY_VARIANT_SMEM asked for)
   size_t dyn_lds;   // dynamic LDS per workgroup: the occupancy cap of NBODY_OPT_WAVES_PER_SIMD (0 = none)
 };
 // all return a hipError_t as int (0 = launched)

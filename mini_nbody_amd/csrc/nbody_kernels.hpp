@@ -990,6 +990,64 @@ __global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_f32(ForceArgs
   finish_rows<float, f4, 1, 16, 0, 1>(seg, lane_row, row_end, me, s, ws_sums, je - jb);
 }
 
+// The same sixteen chains with the sources STAGED THROUGH LDS (round 6; the default of the FPGA order on sixteen waves).  Scalar delivery
+// suits a wave that walks CONSECUTIVE sources (one s_load_dwordx16 brings four); wave k of this kernel wants the sources k, k + 16, ...: one
+// 16-byte scalar load each, eight in flight, every one a scalar-cache miss from a launch's cold start — at the mailbox's sizes the kernel
+// was latency, not issue (N = 1024: 11.3 us for 64 pairs per lane, profiles/r05_mailbox_kernel_trace.txt).  Here the workgroup's 1024
+// threads fetch 1024 consecutive sources with ONE coalesced 16-byte load each into an LDS tile (double-buffered: the next tile's loads are
+// in flight while this one is walked, one barrier per tile), and wave k reads its sources k, k + 16, ... of the tile with broadcast
+// ds_read_b128 (every lane the same address: conflict-free).  Same chains — wave k still adds the sources congruent to k (1024 is a multiple
+// of 16) in ascending order with the same pair_f32 —, same rotation, same tree: the same bits as the scalar form (NBODY_OPT_VARIANT =
+// NBODY_VARIANT_SMEM keeps that one selectable; tests: test_fpga16_order, the rtl_n*.json fixtures).  LDS: 2 x 16 KiB + the 15 KiB join.
+template <int ARITH>
+__global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_lds_f32(ForceArgs a) {
+  NB_WS_LDS(f4, 16);
+  constexpr int TILE = 1024;
+  __shared__ f4 tile[2][TILE];
+  int seg, jb, je, rb;
+  block_segment(a, &seg, &jb, &je, &rb);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int t = (int)threadIdx.x;
+  const int lane_row = a.row0 + rb * 64 + (t & 63);
+  const float eps = soft_f32();
+  const int row_end = a.row0 + a.row_count;
+  f4 me[1];
+  load_rows<float, f4, 1>(a, lane_row, row_end, me);
+  Sums<float, 1> s;
+  s.clear();
+  float px = 0.0f, py = 0.0f, pz = 0.0f;
+  const f4* gsrc = (const f4*)a.src;
+  const f4 none = {0.f, 0.f, 0.f, 0.f};
+  tile[0][t] = (jb + t < je) ? gsrc[jb + t] : none;
+  __syncthreads();
+  int buf = 0;
+  for (int base = jb; base < je; base += TILE) {
+    const int nxt = base + TILE;
+    const bool more = nxt < je;                        // workgroup-uniform
+    f4 pre = none;
+    if (more && nxt + t < je) pre = gsrc[nxt + t];     // in flight while this tile is walked
+    const int cnt = je - base < TILE ? je - base : TILE;
+    const f4* tl = tile[buf];
+    int m = wave;
+    for (; m + 16 * 7 < cnt; m += 16 * 8) {
+      f4 p[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = tl[m + 16 * k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pair_f32<ARITH>(p[k].x, p[k].y, p[k].z, me[0].x, me[0].y, me[0].z, eps, px, py, pz);
+    }
+    for (; m < cnt; m += 16) {
+      const f4 p = tl[m];
+      pair_f32<ARITH>(p.x, p.y, p.z, me[0].x, me[0].y, me[0].z, eps, px, py, pz);
+    }
+    if (more) tile[buf ^ 1][t] = pre;
+    __syncthreads();
+    buf ^= 1;
+  }
+  s.bx[0] = px; s.by[0] = py; s.bz[0] = pz;
+  finish_rows<float, f4, 1, 16, 0, 1>(seg, lane_row, row_end, me, s, ws_sums, je - jb);
+}
+
 // ---------------------------------------------------------------------------
 // fp64 (BASELINE config 5).  SMEM delivery, R bodies per lane.  One sequential sum per segment (fp64 has 29 more
 // bits than the 1e-5 target needs; sum_block is ignored).

@@ -42,7 +42,12 @@ def test_default_line_carries_the_other_baseline_configs():
     assert j["config"]["n_bodies"] == 1 << 20 and j["value"] > 3000 and "extras" not in j, j.get("extras")
     assert j["cpu_baseline"]["value"] > 0 and j["strict_mode"]["value"] > 0
     c = j["configs"]
-    assert set(c) >= {"config2", "config2_lds_tile256", "fp64", "config1", "seconds"} and c["seconds"] < 40
+    assert set(c) >= {"config2", "config2_lds_tile256", "fp64", "config1", "seconds"} and c["seconds"] < 60
+    # every entry carries its own measured host-CPU column, and the LDS entry runs the sweep's best LDS form and names it
+    for key in ("config2", "config2_lds_tile256", "fp64", "config1"):
+        cb = c[key]["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"], (key, cb)
+    assert c["config2_lds_tile256"]["kernel"]["iblock"] == 4 and c["config2_lds_tile256"]["kernel"]["nseg"] == 32 and "best measured" in c["config2_lds_tile256"]["form"]
     for key in ("config2", "config2_lds_tile256"):
         assert c[key]["value"] > 2000 and 0.2 < c[key]["frac"] < 0.7 and c[key]["ms_per_step"] < 3, (key, c[key])
     assert c["config2"]["kernel"]["variant"] == "isa" and c["config2_lds_tile256"]["kernel"]["variant"] == "lds" and c["config2_lds_tile256"]["kernel"]["tile"] == 256

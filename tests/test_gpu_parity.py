@@ -598,6 +598,19 @@ def test_fpga16_order(nb, oracle_fast, engine_factory, wsplit):
             one_lane = eng.forces(pos)
             eng.set_option(nb.OPT_WSPLIT, wsplit)
             assert eng.config["nseg"] == 4 and np.array_equal(bits(eng.forces(pos)), bits(one_lane)), n
+        if wsplit != 1:
+            # round 6: the sixteen-wave form stages its sources through LDS by default (force_fpga16w_lds_f32); NBODY_VARIANT_SMEM keeps
+            # round 4's scalar delivery (force_fpga16w_f32): the same chains, the same bits — one segment and several
+            for jsl, jsub in ((0, 1), (2, 2)):
+                eng.set_option(nb.OPT_JSLICES, jsl)
+                eng.set_option(nb.OPT_JSUB, jsub)
+                eng.set_option(nb.OPT_ARITH, nb.ARITH_REFERENCE_STRICT)
+                eng.set_option(nb.OPT_VARIANT, nb.VARIANT_AUTO)
+                staged = eng.forces(pos)
+                eng.set_option(nb.OPT_VARIANT, nb.VARIANT_SMEM)
+                assert eng.config["wsplit"] == 16 and np.array_equal(bits(eng.forces(pos)), bits(staged)), (n, jsl, jsub)
+                if jsub == 1:
+                    assert np.array_equal(bits(staged), bits(want)), n
 
 
 def test_bodyForce_integrate_config1_shape(nb, oracle_fast, engine_factory):

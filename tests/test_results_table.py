@@ -118,9 +118,12 @@ def test_kernel_source_sha_ignores_the_diagnostic_build(tmp_path, monkeypatch):
 def test_one_gpu_line_with_the_other_baseline_configs(tmp_path):
     """round 5: the driver's N = 1 line also carries `configs` (BASELINE configs 1 and 2 and the fp64 arithmetic, measured after the headline);
     an N > 1 line carries a numeric cpu_baseline of its own"""
-    configs = {"config2": {"workload": "N=65536 fp32, 100 steps, 1 GPU", "value": 4547.0, "ms_per_step": 0.9446, "frac": 0.5781},
-               "config2_lds_tile256": {"workload": "N=65536 fp32, 100 steps, 1 GPU", "value": 4306.0, "ms_per_step": 0.9974, "frac": 0.5475},
-               "fp64": {"workload": "N=262144 fp64, 3 steps, 1 GPU", "value": 1830.0, "ms_per_step": 37.55, "frac": 0.4656, "frac_of_issue_bound": 0.93},
+    cpu2 = {"value": 61.25, "unit": "billion pair-interactions/s", "cores": 256, "kind": "port", "sample": "first 65536 of 65536 rows"}
+    configs = {"config2": {"workload": "N=65536 fp32, 100 steps, 1 GPU", "value": 4547.0, "ms_per_step": 0.9446, "frac": 0.5781, "cpu_baseline": cpu2},
+               "config2_lds_tile256": {"workload": "N=65536 fp32, 100 steps, 1 GPU", "value": 4306.0, "ms_per_step": 0.9974, "frac": 0.5475, "cpu_baseline": cpu2,
+                                       "kernel": {"variant": "lds", "tile": 256, "iblock": 4, "nseg": 32}},
+               "fp64": {"workload": "N=262144 fp64, 3 steps, 1 GPU", "value": 1830.0, "ms_per_step": 37.55, "frac": 0.4656, "frac_of_issue_bound": 0.93,
+                        "cpu_baseline": {"value": 30.5, "cores": 256}},
                "config1": {"workload": "N=4096 fp32, 10 iterations (the first is warm-up), one sequential sum per body", "value": 0.82, "ms_per_step": 20.4,
                            "cpu_value": 1.913, "checksums_equal": True},
                "seconds": 4.2}
@@ -128,7 +131,9 @@ def test_one_gpu_line_with_the_other_baseline_configs(tmp_path):
     json.dump({"runs": [{"parsed": line(1, 4700.0)}, {"parsed": line(2, 9300.0, cpu_baseline={"value": 58.2, "cores": 256})}]}, open(tmp_path / "SCALE_r05.json", "w"))
     t = rt.table(str(tmp_path))
     assert "| BENCH_r05.json | 65536 | fp32 | 1 | 4547 | 57.8 |" in t and "BASELINE configs[1], the engine's default kernel, 0.945 ms/step" in t
-    assert "| BENCH_r05.json | 65536 | fp32 | 1 | 4306 | 54.8 |" in t and "tile 256" in t
+    assert "| BENCH_r05.json | 65536 | fp32 | 1 | 4306 | 54.8 |" in t and "tile 256; 4 bodies per lane, 32 segments" in t
+    # round 6: every configs entry fills the host-CPU column from its own cpu_baseline
+    assert t.count("| 61.2 (256 threads) |") == 2 and "| 30.5 (256 threads) |" in t
     assert "| BENCH_r05.json | 262144 | fp64 | 1 | 1830 | 46.6 | 93.0 |" in t
     assert "| BENCH_r05.json | 4096 | fp32 | 1 | 0.82 |" in t and "1.913 G pairs/s on the host), checksum lines EQUAL" in t
     assert "| 2 | 9300 | 59.0 | 88.5 | 0.989 | 0.020 | rccl | 58.2 (256 threads) |" in t
