@@ -304,7 +304,20 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   // (r03, wall clock per step: 16384 waves in the launch (N = 16384) 68.0 us with the long buffers against 69.5, 20480 waves
   //  101.7 / 102.9, 24576 waves 144.2 / 142.2, 32768 waves 249.6 / 246.6: the switch sits at 88 waves per CU)
   a.long_buffers = g.opt.long_buffers < 0 ? ((long long)grid.x * grid.y * (wg_threads(a.wsplit) / 64) < 88LL * cus ? 1 : 0) : g.opt.long_buffers;
-  nbl::KernelSel sel = {g.fp64, g.variant, R, g.opt.arith, g.tile, g.opt.isa_phase, g.opt.variant != NBODY_VARIANT_SMEM ? 1 : 0, 0};
+  nbl::KernelSel sel = {g.fp64, g.variant, R, g.opt.arith, g.tile, g.opt.isa_phase, g.opt.variant != NBODY_VARIANT_SMEM ? 1 : 0, 0, 0};
+  // The FPGA order with ONE segment (the mailbox's faithful mode) in a launch that would leave CUs idle with 64 rows per workgroup:
+  // sixteen rows x sixteen chains per workgroup instead (force_fpga16r_f32) — the same bits from four times the workgroups.  Up to four
+  // 16-row workgroups per CU (rows < 64 x CUs: there the 64-row form fills every CU too, with a quarter of the source fetches).
+  // NBODY_FPGA_ROWS16 = 0 / 1 overrides (A/B).
+  if (a.fpga16 && !g.fp64 && a.wsplit == 16 && g.nseg == 1 && sel.fpga_lds && a.finish == kFinishDirect) {
+    static const int force_rows16 = [] { const char* e = getenv("NBODY_FPGA_ROWS16"); return (e && *e) ? atoi(e) : -1; }();
+    const bool small_launch = (long long)row_count < 64LL * cus;
+    if (force_rows16 > 0 || (force_rows16 < 0 && small_launch)) {
+      sel.fpga_rows16 = 1;
+      grid = dim3((row_count + 15) / 16, 1, 1);
+      a.xcd_map = 0;
+    }
+  }
   // optional occupancy cap: k workgroups (= k waves per SIMD) per CU by giving each 160 KiB / k of dynamic LDS
   if (g.opt.waves_per_simd > 0 && g.opt.waves_per_simd < 8) {
     const size_t static_lds = (g.variant == NBODY_VARIANT_LDS ? (size_t)g.tile * 32 : 0) + (a.wsplit > 1 ? (size_t)(a.wsplit - 1) * 64 * word_bytes() : 0) +

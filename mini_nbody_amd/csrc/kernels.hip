@@ -105,6 +105,15 @@ NBL_HIDDEN int launch_force_kernel(const KernelSel& s, hipStream_t st, dim3 grid
       default: return launch_k(force_smem_f64<4, 1>, s, st, grid, a);
     }
   }
+  if (a.fpga16 && s.fpga_rows16) {   // small launches of ONE segment: sixteen rows x sixteen chains per 256-thread workgroup (grid.x counts 16-row units)
+    switch (s.arith) {
+      case NBODY_ARITH_REFERENCE: hipLaunchKernelGGL(force_fpga16r_f32<1>, grid, dim3(256), 0, st, a); break;
+      case NBODY_ARITH_STRICT: hipLaunchKernelGGL(force_fpga16r_f32<2>, grid, dim3(256), 0, st, a); break;
+      case NBODY_ARITH_REFERENCE_STRICT: hipLaunchKernelGGL(force_fpga16r_f32<3>, grid, dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL(force_fpga16r_f32<0>, grid, dim3(256), 0, st, a); break;
+    }
+    return (int)hipGetLastError();
+  }
   if (a.fpga16 && a.wsplit == 16 && s.fpga_lds) {   // sources staged through LDS (the default of the sixteen-wave form)
     switch (s.arith) {
       case NBODY_ARITH_REFERENCE: return launch_k(force_fpga16w_lds_f32<1>, s, st, grid, a);

@@ -166,6 +166,7 @@ namespace nbl {
 struct KernelSel {
   int fp64, variant, R, arith, tile, isa_phase;
   int fpga_lds;     // the FPGA order on sixteen waves: 1 = sources staged through LDS (default), 0 = scalar delivery (NBODY_VARIANT_SMEM asked for)
+  int fpga_rows16;  // the FPGA order, one segment, a small launch: 16 rows x 16 chains per 256-thread workgroup (grid.x = 16-row units)
   size_t dyn_lds;   // dynamic LDS per workgroup: the occupancy cap of NBODY_OPT_WAVES_PER_SIMD (0 = none)
 };
 // all return a hipError_t as int (0 = launched)

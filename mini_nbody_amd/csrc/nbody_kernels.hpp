@@ -1048,6 +1048,81 @@ __global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_lds_f32(Force
   finish_rows<float, f4, 1, 16, 0, 1>(seg, lane_row, row_end, me, s, ws_sums, je - jb);
 }
 
+// The FPGA order for SMALL launches (round 6): sixteen ROWS and sixteen chains per workgroup.  With 64 rows per workgroup a pass over N
+// bodies has N / 64 workgroups — N = 1024: sixteen, on sixteen of the 256 CUs, four waves per SIMD; the launch is issue-bound INSIDE those
+// CUs (N = 1024: 5.5 us of issue per SIMD, 11.3 us measured) while 240 CUs idle.  Here a workgroup of 256 threads owns 16 rows: lane l of
+// wave w holds row l mod 16 and chain 4 w + l / 16 — the reference's twelve bodies x sixteen partial sums (S/top_level.vhd:44,
+// S/fxyz.vhd:129-145) with sixteen bodies, one (body, partial sum) per lane.  N / 16 workgroups of four waves: four times the CUs, a quarter
+// of the walk per SIMD.  Sources come through the same double-buffered 1024-body LDS tile (four coalesced loads per thread); a wave reads
+// four consecutive words per step (its four chains), each broadcast to sixteen lanes.  The sixteen sums of a row meet in LDS
+// (part[chain][row]); lane r of wave 0 takes results(t) = part[(count + t) mod 16][r] — zero where no item existed — and adds final_adder's
+// tree.  Same chains, rotation, tree: the same bits.  One segment only (the launch finishes its rows itself): what the mailbox's faithful
+// mode runs (NBODY_OPT_JSUB 1); several segments keep the 64-row kernels, whose tickets count 64-row units.
+template <int ARITH>
+__global__ void __launch_bounds__(256) force_fpga16r_f32(ForceArgs a) {
+  constexpr int TILE = 1024;
+  __shared__ f4 tile[2][TILE];
+  __shared__ f4 part[16][16];
+  const int t = (int)threadIdx.x;
+  const int r = t & 15, c = t >> 4;
+  const int row_end = a.row0 + a.row_count;
+  const int i = a.row0 + (int)blockIdx.x * 16 + r;
+  const f4 me = ((const f4*)a.rows)[i < row_end ? i : row_end - 1];
+  const float eps = soft_f32();
+  int jb, je;
+  segment_bounds(0, 0, a.n_src, 1, 1, &jb, &je);        // the one segment: every source, ascending (S/top_level.vhd:233-254)
+  const f4* gsrc = (const f4*)a.src;
+  const f4 none = {0.f, 0.f, 0.f, 0.f};
+  float px = 0.0f, py = 0.0f, pz = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int j = jb + q * 256 + t; tile[0][q * 256 + t] = j < je ? gsrc[j] : none; }
+  __syncthreads();
+  int buf = 0;
+  for (int base = jb; base < je; base += TILE) {
+    const int nxt = base + TILE;
+    const bool more = nxt < je;                          // workgroup-uniform
+    f4 pre[4] = {none, none, none, none};
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int j = nxt + q * 256 + t; if (j < je) pre[q] = gsrc[j]; }
+    }
+    const int cnt = je - base < TILE ? je - base : TILE;
+    const f4* tl = tile[buf];
+    int m = c;
+    for (; m + 16 * 7 < cnt; m += 16 * 8) {              // (cnt is uniform, c differs by at most 15: the lanes leave this loop within one round)
+      f4 p[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = tl[m + 16 * k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pair_f32<ARITH>(p[k].x, p[k].y, p[k].z, me.x, me.y, me.z, eps, px, py, pz);
+    }
+    for (; m < cnt; m += 16) {
+      const f4 p = tl[m];
+      pair_f32<ARITH>(p.x, p.y, p.z, me.x, me.y, me.z, eps, px, py, pz);
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tile[buf ^ 1][q * 256 + t] = pre[q];
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  const f4 mine = {px, py, pz, 0.f};
+  part[c][r] = mine;
+  __syncthreads();
+  if (t < 16 && i < row_end) {
+    const int count = je - jb;
+    float rx[16], ry[16], rz[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const f4 v = part[(count + k) & 15][t];
+      const bool item = count - 16 + k >= 0;             // results(k) is written as 0.0 when no item reached it (S/fxyz.vhd:177-181)
+      rx[k] = item ? v.x : 0.f; ry[k] = item ? v.y : 0.f; rz[k] = item ? v.z : 0.f;
+    }
+    apply_force<float, f4>(a, i, me, tree16(rx), tree16(ry), tree16(rz));
+  }
+}
+
 // ---------------------------------------------------------------------------
 // fp64 (BASELINE config 5).  SMEM delivery, R bodies per lane.  One sequential sum per segment (fp64 has 29 more
 // bits than the 1e-5 target needs; sum_block is ignored).
