@@ -150,6 +150,56 @@ __device__ __forceinline__ void pair_f32(float xj, float yj, float zj, float xi,
   az = __builtin_fmaf(dz, inv3, az);
 }
 
+// K pairs of one lane against K sources at once, accumulated IN THE ORDER k = 0 .. K-1 — the same values and the same sums as K calls of
+// pair_f32.  Why it exists (round 6): the strict 1/sqrt ends in a wave-uniform branch (rsqrt_strict_f32), and a branch per pair is a
+// scheduling barrier per pair — the compiler cannot interleave the K independent chains, and a launch with one wave per SIMD runs each
+// pair's ~18 dependent operations back to back (N = 4096 in the 16-row FPGA kernel: 220 cycles per pair against 57 of issue).  Here the
+// fast path of all K pairs is straight-line code, the K "not decided" flags are gathered in one mask, and ONE wave-uniform branch per K
+// pairs sends the rare undecided arguments (3e-5 of them) to the IEEE form.  Full-occupancy launches gain nothing (eight waves per SIMD hide
+// the chains: profiles/r05_strict_loop.md); the low-occupancy launches of the mailbox do.
+template <int ARITH, int K>
+__device__ __forceinline__ void pairs_f32(const f4 (&p)[K], float xi, float yi, float zi, float eps, float& ax, float& ay, float& az) {
+  if constexpr (!(ARITH & kArithStrict)) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) pair_f32<ARITH>(p[k].x, p[k].y, p[k].z, xi, yi, zi, eps, ax, ay, az);
+  } else {
+    float dx[K], dy[K], dz[K], d2[K], inv[K];
+    unsigned undecided = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      dx[k] = p[k].x - xi; dy[k] = p[k].y - yi; dz[k] = p[k].z - zi;
+      if constexpr (ARITH & kArithRef) {
+        const float sxy = dx[k] * dx[k] + dy[k] * dy[k];
+        const float sz = __builtin_fmaf(dz[k], dz[k], eps);
+        d2[k] = sxy + sz;
+      } else {
+        d2[k] = __builtin_fmaf(dx[k], dx[k], __builtin_fmaf(dy[k], dy[k], __builtin_fmaf(dz[k], dz[k], eps)));
+      }
+      if (!rsqrt_fast_f32(d2[k], inv[k])) undecided |= 1u << k;
+    }
+    if (__builtin_amdgcn_ballot_w64(undecided != 0u) != 0) {      // wave-uniform, once per K pairs
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool mine = (undecided >> k) & 1u;
+        if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+          float xs = d2[k];
+          asm volatile("" : "+v"(xs));                            // keeps the IEEE form inside the branch (see rsqrt_strict_f32)
+          const float s = rsqrt_ieee_f32(xs);
+          inv[k] = mine ? s : inv[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float inv2 = inv[k] * inv[k];
+      const float inv3 = inv[k] * inv2;
+      ax = __builtin_fmaf(dx[k], inv3, ax);
+      ay = __builtin_fmaf(dy[k], inv3, ay);
+      az = __builtin_fmaf(dz[k], inv3, az);
+    }
+  }
+}
+
 // fp64: x^(-3/2) straight from the v_rsq_f64 seed y (about 2^-24 relative) by ONE third-order step on the cube: with e = 1 - x*y^2,
 //   x^(-3/2) = y^3 (1 - e)^(-3/2) = y^3 (1 + 3/2 e + 15/8 e^2 + 35/16 e^3 + ...),   inv3 = y^3 + y^3 * e * (3/2 + 15/8 e)
 // leaves (35/16) e^3 < 2^-70: full binary64 in SIX operations (round 1: two Newton steps on y, then the cube: nine; rounds 2-3: one
@@ -1033,8 +1083,12 @@ __global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_lds_f32(Force
       f4 p[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) p[k] = tl[m + 16 * k];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pair_f32<ARITH>(p[k].x, p[k].y, p[k].z, me[0].x, me[0].y, me[0].z, eps, px, py, pz);
+      {
+        const f4 (&lo)[4] = *reinterpret_cast<const f4 (*)[4]>(&p[0]);
+        const f4 (&hi)[4] = *reinterpret_cast<const f4 (*)[4]>(&p[4]);
+        pairs_f32<ARITH, 4>(lo, me[0].x, me[0].y, me[0].z, eps, px, py, pz);   // (two groups of four: this kernel lives within 64 VGPRs)
+        pairs_f32<ARITH, 4>(hi, me[0].x, me[0].y, me[0].z, eps, px, py, pz);
+      }
     }
     for (; m < cnt; m += 16) {
       const f4 p = tl[m];
@@ -1093,8 +1147,7 @@ __global__ void __launch_bounds__(256) force_fpga16r_f32(ForceArgs a) {
       f4 p[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) p[k] = tl[m + 16 * k];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pair_f32<ARITH>(p[k].x, p[k].y, p[k].z, me.x, me.y, me.z, eps, px, py, pz);
+      pairs_f32<ARITH, 8>(p, me.x, me.y, me.z, eps, px, py, pz);
     }
     for (; m < cnt; m += 16) {
       const f4 p = tl[m];
