@@ -155,66 +155,31 @@ __device__ __forceinline__ void pair_f32(float xj, float yj, float zj, float xi,
 // scheduling barrier per pair — the compiler cannot interleave the K independent chains, and a launch with one wave per SIMD runs each
 // pair's ~18 dependent operations back to back (N = 4096 in the 16-row FPGA kernel: 220 cycles per pair against 57 of issue).  Here the
 // fast path of all K pairs is straight-line code, the K "not decided" flags are gathered in one mask, and ONE wave-uniform branch per K
-// pairs sends the rare undecided arguments (3e-5 of them) to the IEEE form.  Full-occupancy launches gain nothing (eight waves per SIMD hide
-// the chains: profiles/r05_strict_loop.md); the low-occupancy launches of the mailbox do.
+// pairs sends the rare undecided arguments (3e-5 of them) to the IEEE form.  Measured in the 16-row FPGA kernel, one wave per SIMD
+// (profiles/r06_mailbox_kernel_trace.txt): N = 4096 26.3 -> 21.7 us, N = 1024 8.6 -> 7.3 us.  Forcing all K pairs into lock-step with
+// scheduling barriers between the stages returned nothing more (21.2 us): a wave alone on its SIMD issues one VALU instruction per ~8
+// cycles whatever their dependences.  At full occupancy grouping LOSES (the sixteen-wave kernel at N = 32767 in two groups of four:
+// 487 -> 583 us; eight waves per SIMD hide the chains anyway, profiles/r05_strict_loop.md): only the 16-row kernel uses it.
 template <int ARITH, int K>
 __device__ __forceinline__ void pairs_f32(const f4 (&p)[K], float xi, float yi, float zi, float eps, float& ax, float& ay, float& az) {
   if constexpr (!(ARITH & kArithStrict)) {
 #pragma unroll
     for (int k = 0; k < K; ++k) pair_f32<ARITH>(p[k].x, p[k].y, p[k].z, xi, yi, zi, eps, ax, ay, az);
   } else {
-    // Stage by stage, the K pairs in lock-step: every instruction is independent of the K - 1 before it.  A wave that is alone on its
-    // SIMD issues a DEPENDENT instruction every ~8 cycles; hipcc's own schedule of this code interleaves two pairs (register pressure is
-    // what it minimises), the scheduling barriers make it K.  The operations and their order per pair are rsqrt_fast_f32's and pair_f32's.
-#define NB_STAGE() __builtin_amdgcn_sched_barrier(0)
-    float dx[K], dy[K], dz[K], d2[K], y[K], hi[K], lo[K], e[K], t[K], inv[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { dx[k] = p[k].x - xi; dy[k] = p[k].y - yi; dz[k] = p[k].z - zi; }
-    NB_STAGE();
-    if constexpr (ARITH & kArithRef) {
-      float sx[K], sy[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) { sx[k] = dx[k] * dx[k]; sy[k] = dy[k] * dy[k]; d2[k] = __builtin_fmaf(dz[k], dz[k], eps); }
-      NB_STAGE();
-#pragma unroll
-      for (int k = 0; k < K; ++k) sx[k] = sx[k] + sy[k];
-      NB_STAGE();
-#pragma unroll
-      for (int k = 0; k < K; ++k) d2[k] = sx[k] + d2[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; ++k) d2[k] = __builtin_fmaf(dz[k], dz[k], eps);
-      NB_STAGE();
-#pragma unroll
-      for (int k = 0; k < K; ++k) d2[k] = __builtin_fmaf(dy[k], dy[k], d2[k]);
-      NB_STAGE();
-#pragma unroll
-      for (int k = 0; k < K; ++k) d2[k] = __builtin_fmaf(dx[k], dx[k], d2[k]);
-    }
-    NB_STAGE();
-#pragma unroll
-    for (int k = 0; k < K; ++k) y[k] = __builtin_amdgcn_rsqf(d2[k]);
-    NB_STAGE();
-#pragma unroll
-    for (int k = 0; k < K; ++k) hi[k] = d2[k] * y[k];
-    NB_STAGE();
-#pragma unroll
-    for (int k = 0; k < K; ++k) { lo[k] = __builtin_fmaf(d2[k], y[k], -hi[k]); e[k] = __builtin_fmaf(-hi[k], y[k], 1.0f); }
-    NB_STAGE();
-#pragma unroll
-    for (int k = 0; k < K; ++k) e[k] = __builtin_fmaf(-lo[k], y[k], e[k]);
-    NB_STAGE();
-#pragma unroll
-    for (int k = 0; k < K; ++k) t[k] = y[k] * e[k];
-    NB_STAGE();
+    float dx[K], dy[K], dz[K], d2[K], inv[K];
     unsigned undecided = 0u;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      inv[k] = __builtin_fmaf(t[k], 0.5f + kStrictBand, y[k]);
-      const float r2 = __builtin_fmaf(t[k], 0.5f - kStrictBand, y[k]);
-      if (!(inv[k] == r2)) undecided |= 1u << k;
+      dx[k] = p[k].x - xi; dy[k] = p[k].y - yi; dz[k] = p[k].z - zi;
+      if constexpr (ARITH & kArithRef) {
+        const float sxy = dx[k] * dx[k] + dy[k] * dy[k];
+        const float sz = __builtin_fmaf(dz[k], dz[k], eps);
+        d2[k] = sxy + sz;
+      } else {
+        d2[k] = __builtin_fmaf(dx[k], dx[k], __builtin_fmaf(dy[k], dy[k], __builtin_fmaf(dz[k], dz[k], eps)));
+      }
+      if (!rsqrt_fast_f32(d2[k], inv[k])) undecided |= 1u << k;
     }
-    NB_STAGE();
     if (__builtin_amdgcn_ballot_w64(undecided != 0u) != 0) {      // wave-uniform, once per K pairs
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -222,24 +187,19 @@ __device__ __forceinline__ void pairs_f32(const f4 (&p)[K], float xi, float yi, 
         if (__builtin_amdgcn_ballot_w64(mine) != 0) {
           float xs = d2[k];
           asm volatile("" : "+v"(xs));                            // keeps the IEEE form inside the branch (see rsqrt_strict_f32)
-          const float sq = rsqrt_ieee_f32(xs);
-          inv[k] = mine ? sq : inv[k];
+          const float s = rsqrt_ieee_f32(xs);
+          inv[k] = mine ? s : inv[k];
         }
       }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) hi[k] = inv[k] * inv[k];          // inv2
-    NB_STAGE();
-#pragma unroll
-    for (int k = 0; k < K; ++k) hi[k] = inv[k] * hi[k];           // inv3 = inv * inv2 (S/cube.vhd:66-70)
-    NB_STAGE();
-#pragma unroll
-    for (int k = 0; k < K; ++k) {                                 // the three accumulating chains, sources in ascending order
-      ax = __builtin_fmaf(dx[k], hi[k], ax);
-      ay = __builtin_fmaf(dy[k], hi[k], ay);
-      az = __builtin_fmaf(dz[k], hi[k], az);
+    for (int k = 0; k < K; ++k) {
+      const float inv2 = inv[k] * inv[k];
+      const float inv3 = inv[k] * inv2;
+      ax = __builtin_fmaf(dx[k], inv3, ax);
+      ay = __builtin_fmaf(dy[k], inv3, ay);
+      az = __builtin_fmaf(dz[k], inv3, az);
     }
-#undef NB_STAGE
   }
 }
 
