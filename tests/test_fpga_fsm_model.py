@@ -189,3 +189,42 @@ def test_vi_completion_overtakes_the_last_block_group(n):
     top = TopLevel(ram_image(n + 20, n, 1), fixes=ALL_FIXES)
     assert top.run() is not None
     assert top.cs.writes[-1][0] < top.events("done")[0][0] and all(lanes_of(top, k)[1] == {k} for k in range(1, n + 1))
+
+
+@pytest.mark.parametrize("n", [9, 40, 100])
+def test_the_modelled_rtl_with_numbers_writes_the_fixtures_ram_b_image(oracle, n):
+    """The whole chain in one test: the sequencer + compute_store cycle model decides WHO is summed into WHAT and WHERE it is written
+    (which RAM A word each lane holds, which targets reach which of the sixteen partial sums in which order, which RAM B word takes the
+    result); the oracle's pair arithmetic and final_adder's tree supply the numbers; and the RAM B image that comes out — words 1..N —
+    is, bit for bit, the `forces0` of tests/golden/rtl_n*.json, the exact-rational third statement of the RTL (tests/golden/make_system.py
+    forces_rtl) that the GPU's faithful mailbox reproduces in tests/test_gpu_mailbox.py.  Nothing about the order of summation or the address
+    of a result is assumed here: both are read off the model's RAM B."""
+    import glob
+    import json
+    import os
+
+    import numpy as np
+    import oracle as O
+    path = [f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rtl_*.json")) if json.load(open(f))["n"] == n][0]
+    d = json.load(open(path))
+    words = lambda key: np.array([int(x, 16) for x in d[key]], np.uint32).view(np.float32).reshape(-1, 4)   # noqa: E731
+    pos, want = words("pos0"), words("forces0")
+    top = TopLevel(ram_image(n + 20, n, 1), fixes=ALL_FIXES)
+    assert top.run() is not None and sorted(top.cs.ram_b) == list(range(1, n + 1))
+    image = np.zeros((n + 1, 4), np.float32)
+    for k in range(1, n + 1):
+        din = top.cs.ram_b[k]
+        for dim in range(3):                                            # {Fx, Fy, Fz}: S/compute_store.vhd:213
+            lane, d_, slots = din[dim]
+            assert d_ == dim
+            leaves = np.zeros(16, np.float32)
+            for t, slot in enumerate(slots):
+                if not slot:
+                    continue                                             # no item reached results(t): 0.0 (S/fxyz.vhd:177-181)
+                this_word = slot[0][1][lane]
+                src = np.ascontiguousarray(pos[[j - 1 for j, _ in slot]])               # RAM A word j holds body j (1-based)
+                row = pos[this_word - 1:this_word]
+                leaves[t] = oracle.forces_f32(row, src, d2=O.D2_REFERENCE, rsqrt=O.RSQRT_F64, summ=O.SUM_SEQ)[0, dim]   # one fma chain from 0.0
+            image[k, dim] = oracle.tree16(leaves)                        # S/final_adder.vhd:88-104
+    assert np.array_equal(image[1:].view(np.uint32), want.view(np.uint32))
+    assert not image[0].any()

@@ -378,3 +378,23 @@ def test_the_served_context_is_guarded_against_the_callers_thread(nb):
         assert seen["info"] > 1000 and seen["refused"] > 100, seen
         # ... and the context is the caller's again
         assert lib.nbody_sync() == 0 and np.array_equal(bits(mb.forces(pos_all[:40])), bits(first[40]))
+
+
+def test_mailbox_on_a_context_over_several_devices_keeps_the_address_map(nb, monkeypatch):
+    """A context over several devices keeps its fixed N (NUM_PTS must equal it) and answers through nbody_forces' path; the map is the
+    same: force of body k at word k of the caller's RAM B, word 0 and the words beyond N untouched, word 0 of RAM A rewritten by the host."""
+    monkeypatch.setenv("NBODY_OVERSUBSCRIBE", "1")
+    n = 1000
+    pos, _ = nb.make_bodies(n, seed=17)
+    with nb.NBody(n, ngpus=3) as eng:
+        want = eng.forces(pos)
+        ram_b = np.full((n + 3, 4), SENTINEL, np.uint32).view(np.float32)
+        ram_a = nb.mailbox.encode_request(pos)
+        out = nb.mailbox.run(eng, ram_a, clock_khz=300000, ram_b=ram_b)
+        ctl = nb.mailbox.decode_control(ram_a)
+        assert ctl["begin"] == 0 and ctl["ticks"] >= 1 and untouched(ram_b, n)
+        assert np.array_equal(bits(out), bits(want)) and np.array_equal(bits(ram_b[1:n + 1]), bits(want))
+        bad = nb.mailbox.encode_request(pos[:999])
+        with pytest.raises(nb.NBodyError) as e:
+            nb.mailbox.run(eng, bad, ram_b=ram_b)
+        assert e.value.code == nb._lib.ERR_ARG
