@@ -398,3 +398,42 @@ def test_mailbox_on_a_context_over_several_devices_keeps_the_address_map(nb, mon
         with pytest.raises(nb.NBodyError) as e:
             nb.mailbox.run(eng, bad, ram_b=ram_b)
         assert e.value.code == nb._lib.ERR_ARG
+
+
+HOST_DONE_SCRIPT = r"""
+import sys, glob, json, os
+sys.path.insert(0, %r)
+import numpy as np
+import mini_nbody_amd as nb
+fx = {}
+for f in glob.glob(os.path.join(%r, "tests", "golden", "rtl_*.json")):
+    d = json.load(open(f))
+    w = lambda k: np.array([int(x, 16) for x in d[k]], np.uint32).view(np.float32).reshape(-1, 4)
+    fx[d["n"]] = (w("pos0"), w("forces0"))
+with nb.Mailbox(capacity=512, faithful=True) as mb:
+    for served in (False, True):
+        if served:
+            mb.serve(True, 300000)
+        for n in (9, 100, 40, 0, 9):
+            mb.ram_b.view(np.uint32)[...] = 0xDEADBEEF
+            mb.post(fx[n][0] if n else np.zeros((0, 4), np.float32))
+            out, ticks = mb.wait() if served else mb.run(300000)
+            rb = mb.ram_b.view(np.uint32)
+            ok = ticks >= 1 and mb.ram_a[0, 0] == 0 and np.all(rb[0] == 0xDEADBEEF) and np.all(rb[n + 1:] == 0xDEADBEEF)
+            ok = ok and (n == 0 or np.array_equal(out.view(np.uint32), fx[n][1].view(np.uint32)))
+            print("served" if served else "called", n, "ok" if ok else "BAD", ticks)
+        if served:
+            mb.serve(False)
+"""
+
+
+def test_host_written_completion_is_still_a_working_form(nb):
+    """NBODY_MAILBOX_DONE=host keeps round 5's completion — the host thread waits on the stream and writes word 0 itself, ticks from its
+    own clock — for A/B (profiles/r06_mailbox_rate.txt) and as what serves the requests the device cannot complete.  Same bits, same map."""
+    env = dict(os.environ, NBODY_MAILBOX_DONE="host")
+    p = subprocess.run([sys.executable, "-c", HOST_DONE_SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 10 and all(l.split()[2] == "ok" for l in lines), lines
+    # the host's ticks are its own latency (>= 3 at 300 MHz for >= 7 us), the device's at N = 9 are 2-3: the two forms are told apart by the tick word
+    assert all(int(l.split()[3]) >= 2 for l in lines if l.split()[1] == "9"), lines
