@@ -372,12 +372,13 @@ def test_one_gpu_command_line_goes_through_the_supervisor(tmp_path):
                                 '    print(json.dumps({"metric": "stub", "n_gpus": 1, "worker": os.environ.get(WORKER_ENV), "argv": argv})); '
                                 'print(json.dumps({"metric": "stub", "n_gpus": 1, "second": True, "argv": argv})); return\n'
                                 '    if not os.path.exists(os.path.join(ROOT, "mini_nbody_amd", "libnbody_hip.so")):', 1))
-    r = subprocess.run([sys.executable, str(stub), "--steps", "3"], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ, PYTHONPATH=ROOT)     # (the copy lives outside the repository: mini_nbody_amd/launcher.py is found through the path)
+    r = subprocess.run([sys.executable, str(stub), "--steps", "3"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["second"] is True and lines[0]["argv"] == ["--steps", "3"] and "supervisor_seconds" in lines[0]
     # --in-process: no worker, both lines come from this very process
-    r = subprocess.run([sys.executable, str(stub), "--in-process"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, str(stub), "--in-process"], capture_output=True, text=True, timeout=120, env=env)
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 2 and lines[0]["worker"] is None
 
