@@ -147,10 +147,19 @@ def cpu_baseline(n, seed, fp64, target_s=15.0):
         run(rows2)
         t = time.perf_counter() - t0
         rows = rows2
+    # a small N fits whole in a fraction of the time asked for (N = 65536: 4.3e9 pairs, ~0.1 s — as long as waking 256 threads): the
+    # whole pass is then repeated until about a third of target_s has gone by, and the passes are timed together
+    passes = 1
+    if rows == n and t < target_s / 6.0:
+        passes = int(max(2, min(64, (target_s / 3.0) / max(t, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            run(rows)
+        t = time.perf_counter() - t0
     what = "fp64, sequential-j, 1.0/sqrt" if fp64 else "fp32, sequential-j, 1.0f/sqrtf"
-    return {"value": round(rows * n / t / 1e9, 3), "unit": "billion pair-interactions/s", "cores": cores, "kind": "port",
-            "sample": "oracle/nbody_ref.c (%s), first %d of %d rows x all %d sources, %.1f s, gcc -O3 %s -fopenmp"
-                      % (what, rows, n, n, t, "-march=native" if path else "-march=x86-64-v3")}
+    return {"value": round(passes * rows * n / t / 1e9, 3), "unit": "billion pair-interactions/s", "cores": cores, "kind": "port",
+            "sample": "oracle/nbody_ref.c (%s), first %d of %d rows x all %d sources%s, %.1f s, gcc -O3 %s -fopenmp"
+                      % (what, rows, n, n, " x %d passes" % passes if passes > 1 else "", t, "-march=native" if path else "-march=x86-64-v3")}
 
 
 def cpu_baseline_program(argv, timeout_s):
