@@ -86,7 +86,12 @@ enum {
                               reference's sixteen partial sums of a body on the sixteen waves of a workgroup (wave k walks the
                               sources k, k + 16, ... of the segment; wave 0 adds rotation and tree), 1 keeps all sixteen in one lane
                               (rounds 1-3).  Sixteen times the waves: the mailbox's maximum N = 32767 takes 0.51 ms per pass
-                              instead of 2.56 (NBODY_INFO_WSPLIT then reports 16). */
+                              instead of 2.56 (NBODY_INFO_WSPLIT then reports 16).  Round 6, still the same bits: the sixteen-wave form
+                              stages its sources through LDS (NBODY_OPT_VARIANT = NBODY_VARIANT_SMEM keeps round 4's scalar delivery),
+                              and a ONE-segment launch of fewer than 64 x CUs rows — the mailbox's faithful mode below N = 16384 — gives a
+                              256-thread workgroup 16 rows x 16 partial sums, one (row, partial sum) per lane: four times the workgroups
+                              where 64 rows per workgroup would leave CUs idle (N = 1024: 16 workgroups -> 64; NBODY_INFO_WSPLIT still
+                              reports 16: sixteen partial sums per row, side by side). */
   NBODY_OPT_ISA_PHASE = 10 /* NBODY_VARIANT_ISA: which generated form of the hand-scheduled loop runs (tools/gen_force_loop.py).
                               1 = the product loop (default); 0 = the same instructions placed one 4-byte phase off (-27 %, kept
                               so that the placement effect can be re-measured).  fp64: 1 = the product loop (VALU instructions at
