@@ -4,7 +4,8 @@
 INPUTS are the stimuli of the reference's own testbenches
 (/root/reference/vec_add.srcs/sim_1/new/, "T/"), restated here as data:
   kat_dxy        T/tb_dxy.vhd:450,458 (x_this), :575,584 (x_target), :701,710 (y_this), :827,836 (y_target)
-  kat_dxyz_soft  T/tb_dxyz_soft.vhd:525 (single), :532 with increments :509-511 (ramp of 5)
+  kat_dxyz_soft  T/tb_dxyz_soft.vhd:525 (single), :532 with increments :509-511 (ramp of 5); T/tb_dxyz_soft_new.vhd:520 (single), :527 with
+                 increments :505-507 (ramp of 100) — the stimuli of the work-in-progress testbench that does not parse, as written
   kat_rsqrt      T/tb_sqrt.vhd:494 (single), :503 (ramp 0.1 .. 10.0), :528-541 (special values)
 The reals are converted to binary32 exactly as the testbench helper does
 (real_to_flt, e.g. S/dzsoft.vhd:62-147: normalise, integer(mant * 2**23) with
@@ -180,13 +181,30 @@ def kat_dxyz_soft():
         v1 += 1.0
         v3 += 2.0
         v5 += 3.0
+    # The work-in-progress copy of that testbench, T/tb_dxyz_soft_new.vhd — it does not parse —, carries the stimuli its
+    # author was about to run: one procedure driving all six operands (:451-466; it assigns y_this twice and z_this never: read as meant,
+    # this = (data1, data3, data5), target = (data2, data4, data6)), a single operation this = (1, 2, 3), target = (0, 0, 0) (:520) and a
+    # ramp of 100 with the three `this` components incremented by 2.0 (:527 with :505-507).  The zero targets go through real_to_flt(..,
+    # normal), which the helper itself rejects; the vectors keep them as +0, as for tb_dxy.
+    case("new:single", (r(1.0), r(2.0), r(3.0)), (0, 0, 0))
+    n1, n3, n5 = 1.0, 2.0, 3.0
+    for k in range(100):
+        case("new:ramp[%d]" % k, (r(n1), r(n3), r(n5)), (0, 0, 0))
+        n1 += 2.0
+        n3 += 2.0
+        n5 += 2.0
+    for c in cases[7:]:
+        k = int(c["label"][9:-1])
+        # small integers: every product and sum is exact, eps vanishes in the rounding of dz^2 + eps
+        assert bits_f32(int(c["dist_sqr"], 16)) == float((1 + 2 * k) ** 2 + (2 + 2 * k) ** 2 + (3 + 2 * k) ** 2) == bits_f32(int(c["dist_sqr_fma3"], 16))
+    assert bits_f32(int(cases[6]["dist_sqr"], 16)) == 14.0
     want = [14.0, None, 14.0, 56.0, 126.0, 224.0]
     for c, w in zip(cases, want):
         if w is None:
             assert int(c["dist_sqr"], 16) == SOFT          # the self-interaction case: d2 = eps exactly
         else:
             assert bits_f32(int(c["dist_sqr"], 16)) == w
-    return dict(source="T/tb_dxyz_soft.vhd:509-511,525,532", entity="S/dxyz_soft.vhd:87-93,149-150", cases=cases)
+    return dict(source="T/tb_dxyz_soft.vhd:509-511,525,532; T/tb_dxyz_soft_new.vhd:451-466,505-507,520,527", entity="S/dxyz_soft.vhd:87-93,149-150", cases=cases)
 
 
 def kat_rsqrt():

@@ -42,6 +42,7 @@ def test_kat_dxy(oracle):
 
 def test_kat_dxyz_soft(oracle):
     d = load("kat_dxyz_soft")
+    assert len(d["cases"]) == 6 + 101        # tb_dxyz_soft's 1 + 5, and the 1 + 100 its unfinished successor was about to drive
     for c in d["cases"]:
         this = [f(h) for h in c["this"]]
         tgt = [f(h) for h in c["target"]]
