@@ -1045,13 +1045,15 @@ __global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_f32(ForceArgs
 
 // The same sixteen chains with the sources STAGED THROUGH LDS (round 6; the default of the FPGA order on sixteen waves).  Scalar delivery
 // suits a wave that walks CONSECUTIVE sources (one s_load_dwordx16 brings four); wave k of this kernel wants the sources k, k + 16, ...: one
-// 16-byte scalar load each, eight in flight, every one a scalar-cache miss from a launch's cold start — at the mailbox's sizes the kernel
-// was latency, not issue (N = 1024: 11.3 us for 64 pairs per lane, profiles/r05_mailbox_kernel_trace.txt).  Here the workgroup's 1024
+// 16-byte scalar load each, eight in flight, every one a scalar-cache miss from a launch's cold start.  Here the workgroup's 1024
 // threads fetch 1024 consecutive sources with ONE coalesced 16-byte load each into an LDS tile (double-buffered: the next tile's loads are
 // in flight while this one is walked, one barrier per tile), and wave k reads its sources k, k + 16, ... of the tile with broadcast
 // ds_read_b128 (every lane the same address: conflict-free).  Same chains — wave k still adds the sources congruent to k (1024 is a multiple
 // of 16) in ascending order with the same pair_f32 —, same rotation, same tree: the same bits as the scalar form (NBODY_OPT_VARIANT =
 // NBODY_VARIANT_SMEM keeps that one selectable; tests: test_fpga16_order, the rtl_n*.json fixtures).  LDS: 2 x 16 KiB + the 15 KiB join.
+// Measured (profiles/r06_mailbox_rate.txt, block C's header): LEVEL with the scalar form at every size — N = 1024 11.3 us either way: the
+// launch was not load-bound but issue-bound inside its sixteen CUs, which is what force_fpga16r_f32 below is for.  Kept as the default because
+// the 16-row kernel shares its tile code and a launch's first loads no longer serialise on the scalar cache.
 template <int ARITH>
 __global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_lds_f32(ForceArgs a) {
   NB_WS_LDS(f4, 16);

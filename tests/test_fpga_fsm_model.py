@@ -10,7 +10,7 @@ and two more this model found:
   (v)   THIS_PTR is log_ram_depth bits wide: a request whose last block-group reaches lane index 2^15 wraps it, `THIS_PTR > NUM_PTS`
         never becomes true and the pass never ends — NUM_PTS >= 32761 at the RTL's ram_depth                        :45-46, 189, 194
   (vi)  block_setup tests `THIS_PTR > NUM_PTS` BEFORE it tests STORE_BUSY: `complete` — ticks, BEGIN cleared, RESET_STORE — happens
-        while the LAST block-group is still in the arithmetic pipeline; its forces are stored ~190 clocks after "done", and at
+        while the LAST block-group is still in the arithmetic pipeline; its forces are stored 145-170 clocks after word 0 was rewritten, and at
         words 1..12 (STORE_PTR was just reset), on top of the first block-group's                                   :189-193, 224-225
 With four one-line repairs ("ptr_init", "poll_word0", "clear_begin", "drain_first") the same RTL runs the protocol the header describes: bodies at
 words 1..N of RAM A, forces at words 1..N of RAM B (word 0 never written), every body summed over targets 1..N in ascending order with
