@@ -262,6 +262,7 @@ void fill_args(Local& L, ForceArgs& a, int row0, int row_count, const Finish& fi
   memset(&a, 0, sizeof(a));
   a.src = L.pos[L.cur];
   a.rows = word_ptr(L.pos[L.cur], (size_t)L.first);
+  if (L.src_direct) { a.src = L.src_direct; a.rows = L.src_direct; }   // (one-rank mailbox request: first = 0)
   a.partial = L.partial;
   a.vel = L.vel;
   a.pos_next_rows = word_ptr(L.pos[L.cur ^ 1], (size_t)L.first);
@@ -279,6 +280,13 @@ void fill_args(Local& L, ForceArgs& a, int row0, int row_count, const Finish& fi
 }
 
 }  // namespace
+
+bool takes_rows16(int row_count) {
+  if (g.fp64 || g.opt.sum_order != NBODY_SUM_FPGA16 || g.wsplit != 16 || g.nseg != 1 || g.opt.variant == NBODY_VARIANT_SMEM) return false;
+  static const int force_rows16 = [] { const char* e = getenv("NBODY_FPGA_ROWS16"); return (e && *e) ? atoi(e) : -1; }();
+  const int cus = g.cu_count > 0 ? g.cu_count : 256;
+  return force_rows16 > 0 || (force_rows16 < 0 && (long long)row_count < 64LL * cus);
+}
 
 // Launch the force kernel of local L for rows [row0, row0+row_count) against `nsl` source slices
 // starting at slice_start and descending (ring arrival order).  A step may take several launches (own slice, then
@@ -309,14 +317,11 @@ int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, co
   // sixteen rows x sixteen chains per workgroup instead (force_fpga16r_f32) — the same bits from four times the workgroups.  Up to four
   // 16-row workgroups per CU (rows < 64 x CUs: there the 64-row form fills every CU too, with a quarter of the source fetches).
   // NBODY_FPGA_ROWS16 = 0 / 1 overrides (A/B).
-  if (a.fpga16 && !g.fp64 && a.wsplit == 16 && g.nseg == 1 && sel.fpga_lds && a.finish == kFinishDirect) {
-    static const int force_rows16 = [] { const char* e = getenv("NBODY_FPGA_ROWS16"); return (e && *e) ? atoi(e) : -1; }();
-    const bool small_launch = (long long)row_count < 64LL * cus;
-    if (force_rows16 > 0 || (force_rows16 < 0 && small_launch)) {
-      sel.fpga_rows16 = 1;
-      grid = dim3((row_count + 15) / 16, 1, 1);
-      a.xcd_map = 0;
-    }
+  if (takes_rows16(row_count)) {
+    sel.fpga_rows16 = 1;
+    grid = dim3((row_count + 15) / 16, 1, 1);
+    a.xcd_map = 0;
+    a.t0_stamp = L.t0_stamp;
   }
   // optional occupancy cap: k workgroups (= k waves per SIMD) per CU by giving each 160 KiB / k of dynamic LDS
   if (g.opt.waves_per_simd > 0 && g.opt.waves_per_simd < 8) {

@@ -37,6 +37,10 @@ unsigned mb_seq_next = 0;       // sequence number of the last request whose com
 int mb_rt_khz = 100000;         // rate of s_memrealtime (100 MHz on gfx950; hipDeviceAttributeWallClockRate)
 int mb_done_by_device = 1;      // NBODY_MAILBOX_DONE=host: the host thread writes word 0 after hipStreamQuery says so (round 5's form; A/B)
 unsigned mb_since_query = 0;
+int mb_direct_max = 256;        // requests of at most this many bodies whose force launch is the 16-row FPGA kernel read RAM A from that kernel: no
+                                // ingest launch (NBODY_MAILBOX_DIRECT_MAX; 0 = always ingest).  Measured on one box, faithful mode
+                                // (profiles/r06_mailbox_rate.txt block G): N = 9 15.5 -> 12.5 us, N = 100 16.5 -> 13.8; N = 1024 20.0 -> 21.2 (every one of
+                                // its 64 workgroups would read 16 KiB over PCIe): hence 256
 
 int mailbox_rams() {   // RAM A and RAM B: capacity + 1 words each (+ slack), pinned, mapped, coherent
   if (mb_a && mb_b && mb_seq && mb_t0_dev) return NBODY_OK;
@@ -56,6 +60,8 @@ int mailbox_rams() {   // RAM A and RAM B: capacity + 1 words each (+ slack), pi
   else (void)hipGetLastError();
   const char* e = getenv("NBODY_MAILBOX_DONE");
   mb_done_by_device = !(e && !strcmp(e, "host"));
+  const char* dm = getenv("NBODY_MAILBOX_DIRECT_MAX");
+  if (dm && *dm) mb_direct_max = atoi(dm);
   return NBODY_OK;
 }
 
@@ -122,7 +128,11 @@ int wait_seq(hipStream_t stream, unsigned seq) {
 // (and its combine), and — device-written completion — the one-wave launch that rewrites word 0
 int mailbox_launches(Local& L, int num_pts, bool done_by_device, unsigned seq, int clock_khz) {
   // bodies are words 1..N                                              S/top_level.vhd:55, 206-208
-  HIPC((hipError_t)nbl::launch_ingest_kernel(L.compute, L.pos[L.cur], (const char*)mb_a_dev + 16, num_pts, done_by_device ? mb_t0_dev : nullptr));
+  // A handful of bodies in the faithful mode: the 16-row kernel reads RAM A itself (its tile loads ARE the PCIe reads) and stamps the tick
+  // count's start; everything else goes through the ingest launch, which reads RAM A once for all workgroups.
+  const bool direct = done_by_device && num_pts <= mb_direct_max && takes_rows16(num_pts);
+  if (direct) { L.src_direct = (const char*)mb_a_dev + 16; L.t0_stamp = mb_t0_dev; }
+  else HIPC((hipError_t)nbl::launch_ingest_kernel(L.compute, L.pos[L.cur], (const char*)mb_a_dev + 16, num_pts, done_by_device ? mb_t0_dev : nullptr));
   // RAM B's write port: the force launch (or its combine) stores {Fx, Fy, Fz, 0} of body k at word k itself — row k - 1 of the launch
   // goes to force_dst[k - 1] and force_dst is word 1 —; word 0 and the words beyond N are never written       S/compute_store.vhd:213, 221-242
   const Finish fin = {false, false, true};
@@ -130,6 +140,7 @@ int mailbox_launches(Local& L, int num_pts, bool done_by_device, unsigned seq, i
   int rc = launch_force(L, 0, num_pts, g.nslices - 1, g.nslices, fin, 0.f, 0.0);
   if (!rc) rc = launch_combine(L, 0, num_pts, fin, 0.f, 0.0);
   L.force_dst = nullptr;
+  L.src_direct = nullptr; L.t0_stamp = nullptr;
   if (rc || !done_by_device) return rc;
   HIPC((hipError_t)nbl::launch_mailbox_done_kernel(L.compute, mb_a_dev, mb_seq_dev, mb_t0_dev, seq, (unsigned)clock_khz, (unsigned)mb_rt_khz));
   return NBODY_OK;

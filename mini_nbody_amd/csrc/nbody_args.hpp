@@ -55,6 +55,9 @@ struct ForceArgs {
                         // fp64) regions of different waves/workgroups never share a cache line
   float dt;
   double dt64;
+  // APPENDED (the hand-scheduled kernels read the fields above at fixed offsets): where the launch's first wave stamps the real-time counter
+  // — the start of a mailbox request's tick count when the request has no ingest launch (force_fpga16r_f32 reading RAM A itself); null otherwise
+  unsigned long long* t0_stamp;
 };
 
 // slice q of P over n: [first(q), first(q+1)), balanced

@@ -68,6 +68,8 @@ struct Local {
   unsigned* tickets = nullptr;         // arrival counters: one per wave of every block of 256 rows
   void* force = nullptr;
   void* force_dst = nullptr;           // where a launch stores {Fx,Fy,Fz,0} instead of `force` (a mailbox request: RAM B itself)
+  const void* src_direct = nullptr;    // a mailbox request of a handful of bodies: sources and rows read from RAM A itself (no ingest launch) ...
+  unsigned long long* t0_stamp = nullptr;   // ... and the launch's first wave stamps the tick count's start here (ForceArgs::t0_stamp)
   void* full_scratch = nullptr;        // N words: all-gather of a sharded array for the host (multi-process)
   int cur = 0;
   bool all_present = true;             // pos[cur] holds every slice
@@ -139,6 +141,8 @@ int timer_drain(EventTimer& T, int keep);
 // the force kernel of local L for rows [row0, row0 + row_count) against `nsl` source slices starting at slice_start and descending
 int launch_force(Local& L, int row0, int row_count, int slice_start, int nsl, const Finish& fin, float dt, double dt64);
 int launch_combine(Local& L, int row0, int row_count, const Finish& fin, float dt, double dt64);
+// launch_force would take the 16-row FPGA kernel (force_fpga16r_f32) for a launch of row_count rows in the configuration as it stands
+bool takes_rows16(int row_count);
 int sync_all();
 int complete_positions();
 int forces_impl(const void* pos_words, void* force_words, int n);

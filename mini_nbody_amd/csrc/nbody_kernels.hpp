@@ -1113,12 +1113,15 @@ __global__ void __launch_bounds__(wg_threads(16), 8) force_fpga16w_lds_f32(Force
 // (part[chain][row]); lane r of wave 0 takes results(t) = part[(count + t) mod 16][r] — zero where no item existed — and adds final_adder's
 // tree.  Same chains, rotation, tree: the same bits.  One segment only (the launch finishes its rows itself): what the mailbox's faithful
 // mode runs (NBODY_OPT_JSUB 1); several segments keep the 64-row kernels, whose tickets count 64-row units.
+// a.src / a.rows may be RAM A itself (pinned host memory): for a handful of bodies the mailbox skips its ingest launch and this kernel's
+// coalesced tile loads are the PCIe reads (a few workgroups x N x 16 bytes); its first wave then stamps the tick count's start (t0_stamp).
 template <int ARITH>
 __global__ void __launch_bounds__(256) force_fpga16r_f32(ForceArgs a) {
   constexpr int TILE = 1024;
   __shared__ f4 tile[2][TILE];
   __shared__ f4 part[16][16];
   const int t = (int)threadIdx.x;
+  if (a.t0_stamp && blockIdx.x == 0 && t == 0) *a.t0_stamp = __builtin_amdgcn_s_memrealtime();   // a mailbox request without an ingest launch starts its ticks here
   const int r = t & 15, c = t >> 4;
   const int row_end = a.row0 + a.row_count;
   const int i = a.row0 + (int)blockIdx.x * 16 + r;

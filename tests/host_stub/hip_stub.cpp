@@ -100,7 +100,7 @@ namespace nbl {
 bool diag_build() { return false; }
 int launch_force_kernel(const KernelSel& k, hipStream_t, dim3 grid, const ForceArgs& a) {
   const int fp64 = k.fp64, ny = k.fpga_rows16 ? 1 : (int)grid.y;
-  return enqueue([=] { if (fp64) force<double>(a, ny); else force<float>(a, ny); });
+  return enqueue([=] { if (a.t0_stamp) *a.t0_stamp = (unsigned long long)(now_ms() * 1e5); if (fp64) force<double>(a, ny); else force<float>(a, ny); });
 }
 int launch_combine_kernel(int fp64, hipStream_t, dim3, const ForceArgs& a) {
   return enqueue([=] { if (fp64) combine_rows<double>(a, a.row0, a.row0 + a.row_count); else combine_rows<float>(a, a.row0, a.row0 + a.row_count); });
